@@ -1,0 +1,202 @@
+// rt_attention_fwd — joint text+image attention of the MMDiT blocks: softmax(Q·Kᵀ·scale)·V, non-causal,
+// no mask, head dim 128, bf16 in/out, fp32 scores/statistics/accumulators. Flash-style: the S×S score
+// matrix never leaves the CU. Reference: torch SDPA as called by diffusers' FluxAttnProcessor (SURVEY.md
+// Appendix A.1 step 6 / A.2), reached from controlnet_flux.py:343-348,376-380 and PIPE:1092.
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); wave w owns query rows 32w..32w+31 for the whole
+// key sweep. Keys/values arrive in 64-row tiles by LDS-DMA into a 2-deep ring (K 16 KiB + V 16 KiB per slot).
+//
+// Both products run on v_mfma_f32_32x32x16_bf16 with the QUERY index on the lane:
+//   Sᵀ[key][q]  = K · Qᵀ      A = K rows from LDS (ds_read_b128), B = Q rows held in registers
+//   Oᵀ[d][q]   += Vᵀ · Pᵀ     A = Vᵀ via ds_read_b64_tr_b16 (hardware transpose), B = the Sᵀ accumulator
+//                             registers themselves, exponentiated and packed to bf16 (no LDS round trip)
+// so the softmax max/sum of a query row are lane-local apart from one lane<->lane+32 exchange, and the
+// per-row rescale of O is a per-lane scalar multiply.
+//
+// LDS image of a K or V tile: 64 rows × 256 B; 16-B chunk c of row r lives at 256·r + 16·(c ^ f(r)),
+// f(r) = ((r&3)<<2) | ((r>>2)&3): conflict-free for the row reads (K) and the transposed reads (V).
+// LDS-DMA writes lane-linear, so the XOR is applied to each lane's source address.
+#include "rt_common.h"
+
+namespace {
+
+constexpr int DH = 128;
+constexpr int BQ = 128;       // query rows per workgroup
+constexpr int BKV = 64;       // keys per tile
+constexpr int TILE_B = BKV * DH * 2;   // 16 KiB
+constexpr int ATT_THREADS = 256;
+
+__device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* O,
+    int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, int S, int H, float scale_log2) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // [slot][K|V]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * BQ;
+
+  const bf16_t* Qb = Q + b * stride_b + head * DH;
+  const bf16_t* Kb = K + b * stride_b + head * DH;
+  const bf16_t* Vb = V + b * stride_b + head * DH;
+
+  // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7]
+  bf16x8 qf[8];
+  {
+    const int qrow = min(q0 + wave * 32 + l31, S - 1);
+    const bf16_t* qp = Qb + (int64_t)qrow * ld + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+
+  // ---- staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V
+  const int srow = lane >> 4;                 // row inside a piece
+  const int spc = lane & 15;                  // physical chunk written by this lane
+  auto stage = [&](int slot, int kv0) {
+    char* kb = smem + slot * 2 * TILE_B;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (wave * 4 + p) * 4 + srow;          // row in tile
+      const int lc = spc ^ swz(r);                       // logical chunk to fetch
+      const int64_t grow = min(kv0 + r, S - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Kb + grow * ld + lc * 8), LDS_PTR(kb + (wave * 4 + p) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Vb + grow * ld + lc * 8), LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // K row read: row = 32kt + l31, chunk = 2ks + hh
+  int koff[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) koff[kt] = (kt * 32 + l31) * 256;
+  const int ksw = swz(l31);                   // swz depends on row & 15 only; 32kt keeps it
+  // V transposed read: group g = lane>>4 (hh = g>>1), lane 4q+p supplies row r0+q, chunk c0+(p>>1), half p&1
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tg1 = (lane >> 4) & 1;
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (S + BKV - 1) / BKV;
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); slot (t+1)&1 is free
+    if (t + 1 < ntiles) stage((t + 1) & 1, (t + 1) * BKV);
+    const char* kb = smem + (t & 1) * 2 * TILE_B;
+    const char* vb = kb + TILE_B;
+
+    // ---- Sᵀ = K·Qᵀ : two 32-key tiles
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt] + (((2 * ks + hh) ^ ksw) << 4));
+        s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kt], 0, 0, 0);
+      }
+    }
+    // key of s_acc[kt][r]: 64t + 32kt + (r&3) + 8(r>>2) + 4hh
+    if ((t + 1) * BKV > S) {                   // ragged last tile: mask keys >= S (wave-uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * BKV + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= S) s_acc[kt][r] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (log2 domain); the row's other 32 keys live in lane ^ 32
+    float mx = s_acc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * scale_log2);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = exp2f(s_acc[kt][8 * s + j] * scale_log2 - m_new);
+          psum += p;
+          pf[kt][s][j] = (__bf16)p;
+        }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+
+    // ---- Oᵀ += Vᵀ·Pᵀ : element j of lane-half hh of k-step (kt,s) is key 32kt + 16s + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int r0 = kt * 32 + s * 16 + 4 * hh + tq;           // row this lane addresses (first 4-key block)
+        const int r1 = r0 + 8;                                    // second block
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int ch = dt * 4 + tg1 * 2 + (tp >> 1);
+          const s16x4 lo = tr_read(vb + r0 * 256 + ((ch ^ swz(r0)) << 4) + 8 * (tp & 1));
+          const s16x4 hi = tr_read(vb + r1 * 256 + ((ch ^ swz(r1)) << 4) + 8 * (tp & 1));
+          const bf16x8 vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi),
+                                                    0, 1, 2, 3, 4, 5, 6, 7);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s], o_acc[dt], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = 32dt + (r&3) + 8(r>>2) + 4hh
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + wave * 32 + l31;
+  if (qrow < S) {
+    bf16_t* op = O + b * stride_ob + (int64_t)qrow * ldo + head * DH + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b,
+                                int64_t ldo, int64_t stride_ob, int32_t B, int32_t S, int32_t H, float scale,
+                                void* stream) {
+  if (!q || !k || !v || !o || B < 1 || S < 1 || H < 1) return RT_E_BADARG;
+  if (!RT_ALIGNED(q, 16) || !RT_ALIGNED(k, 16) || !RT_ALIGNED(v, 16) || !RT_ALIGNED(o, 8) || ld % 8 || stride_b % 8 ||
+      ldo % 4 || stride_ob % 4)
+    return RT_E_ALIGN;
+  if (ld < (int64_t)H * DH || ldo < (int64_t)H * DH) return RT_E_SHAPE;
+  const dim3 grid((S + BQ - 1) / BQ, H, B);
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,
+                     scale * 1.4426950408889634f);
+  return rt_hip_status();
+}

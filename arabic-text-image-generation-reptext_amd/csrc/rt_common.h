@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels. CDNA4 only: wave = 64 lanes, MFMA, LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "reptext_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define RT_WAVE 64
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 at -O3).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// GELU tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))  == x * sigmoid(2u)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int rt_hip_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? RT_OK : (int)e;
+}
+#define RT_ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)

@@ -1,0 +1,264 @@
+"""Tensor-level wrappers over the C ABI (native.py). PyTorch supplies device memory and the stream only.
+
+Every function validates device/dtype/contiguity, then enqueues ONE native call on torch's current HIP
+stream. Nothing here computes with torch ops; a CPU tensor is an error, not a fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import native
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None) -> Optional[int]:
+    return None if t is None else _dev(t, name, dtype)
+
+
+def _rowmajor2d(t: torch.Tensor, name: str):
+    """Return (rows, cols, ld) for a 2-D view whose last dim is unit-stride."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+@dataclass
+class LinearProblem:
+    """One group of rt_gemm_bf16: out = epilogue(a @ w.T + bias). 2-D row-major views (unit inner stride).
+
+    a [M,K] bf16, w [N,K] bf16, out [M,N] bf16|f32. gate f32 [M/rows_per_batch, >=N]; res same dtype/shape as
+    out (may alias); add2 bf16 [M,N]; rowscale f32 [rows_per_batch]."""
+
+    a: torch.Tensor
+    w: torch.Tensor
+    out: torch.Tensor
+    bias: Optional[torch.Tensor] = None
+    gate: Optional[torch.Tensor] = None
+    res: Optional[torch.Tensor] = None
+    add2: Optional[torch.Tensor] = None
+    rowscale: Optional[torch.Tensor] = None
+    rows_per_batch: int = 0
+    gelu_from: Optional[int] = None
+    alpha: float = 1.0
+
+    def to_group(self) -> native.GemmGroup:
+        M, K, lda = _rowmajor2d(self.a, "a")
+        N, Kw, ldw = _rowmajor2d(self.w, "w")
+        Mo, No, ldc = _rowmajor2d(self.out, "out")
+        if Kw != K or Mo != M or No != N:
+            raise ValueError(f"linear shapes mismatch: a{tuple(self.a.shape)} w{tuple(self.w.shape)} out{tuple(self.out.shape)}")
+        g = native.GemmGroup()
+        g.A = _dev(self.a, "a", BF16)
+        g.W = _dev(self.w, "w", BF16)
+        if self.out.dtype not in (BF16, F32):
+            raise TypeError("out must be bf16 or f32")
+        g.C = _dev(self.out, "out")
+        g.out_f32 = 1 if self.out.dtype == F32 else 0
+        g.lda, g.ldw, g.ldc = lda, ldw, ldc
+        g.M, g.N, g.K, g.batch = M, N, K, 1
+        g.bias = _opt(self.bias, "bias", BF16)
+        if self.bias is not None and self.bias.numel() != N:
+            raise ValueError("bias length != N")
+        rpb = self.rows_per_batch
+        if self.gate is not None:
+            gr, gc, gld = _rowmajor2d(self.gate, "gate")
+            rows = rpb if rpb > 0 else M
+            if gc < N or gr * rows < M:
+                raise ValueError("gate too small for this problem")
+            g.gate = _dev(self.gate, "gate", F32)
+            g.gate_ld = gld
+        if self.res is not None:
+            rr, rc, ldr = _rowmajor2d(self.res, "res")
+            if (rr, rc) != (M, N) or self.res.dtype != self.out.dtype:
+                raise ValueError("res must match out in shape and dtype")
+            g.res = _dev(self.res, "res")
+            g.ldr = ldr
+        if self.add2 is not None:
+            ar, ac, ld2 = _rowmajor2d(self.add2, "add2")
+            if (ar, ac) != (M, N):
+                raise ValueError("add2 must be [M,N]")
+            g.add2 = _dev(self.add2, "add2", BF16)
+            g.ld2 = ld2
+        if self.rowscale is not None:
+            rows = rpb if rpb > 0 else M
+            if self.rowscale.numel() != rows or not self.rowscale.is_contiguous():
+                raise ValueError("rowscale must be contiguous with rows_per_batch elements")
+            g.rowscale = _dev(self.rowscale, "rowscale", F32)
+        g.rows_per_batch = rpb
+        g.gelu_from = N if self.gelu_from is None else int(self.gelu_from)
+        g.alpha = float(self.alpha)
+        return g
+
+
+def linear_grouped(problems: Sequence[LinearProblem]) -> None:
+    """Enqueue up to RT_GEMM_MAX_GROUPS independent linears as ONE launch (image + text stream of a block)."""
+    n = len(problems)
+    if not 1 <= n <= native.RT_GEMM_MAX_GROUPS:
+        raise ValueError(f"1..{native.RT_GEMM_MAX_GROUPS} problems per launch")
+    arr = (native.GemmGroup * n)(*[p.to_group() for p in problems])
+    native.check("rt_gemm_bf16", native.load().rt_gemm_bf16(arr, n, _stream()))
+
+
+def linear(a, w, out, **kw) -> torch.Tensor:
+    linear_grouped([LinearProblem(a, w, out, **kw)])
+    return out
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, silu_in=False,
+         silu_out=False, accumulate=False) -> torch.Tensor:
+    """out[b,n] (+)= post(sum_k pre(x[b,k]) w[n,k] + bias[n]); x,out f32, w,bias bf16."""
+    B, K, ldx = _rowmajor2d(x, "x")
+    N, Kw, ldw = _rowmajor2d(w, "w")
+    Bo, No, ldy = _rowmajor2d(out, "out")
+    if Kw != K or Bo != B or No != N:
+        raise ValueError("gemv shapes mismatch")
+    lib = native.load()
+    step = 4
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        native.check("rt_gemv_bf16w", lib.rt_gemv_bf16w(
+            _dev(x, "x", F32) + b0 * ldx * 4, ldx, _dev(w, "w", BF16), ldw, _opt(bias, "bias", BF16),
+            _dev(out, "out", F32) + b0 * ldy * 4, ldy, nb, N, K, int(silu_in), int(silu_out), int(accumulate), _stream()))
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int = 256) -> torch.Tensor:
+    t = t.contiguous()
+    out = torch.empty(t.numel(), dim, device=t.device, dtype=F32)
+    native.check("rt_timestep_embedding", native.load().rt_timestep_embedding(_dev(t, "t", F32), out.data_ptr(), t.numel(), dim, _stream()))
+    return out
+
+
+def rope_table(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10000.0):
+    ids = ids.to(F32).contiguous()
+    S = ids.shape[0]
+    D = int(sum(axes_dim))
+    cos = torch.empty(S, D, device=ids.device, dtype=F32)
+    sin = torch.empty(S, D, device=ids.device, dtype=F32)
+    ax = (C.c_int32 * 3)(*[int(a) for a in axes_dim])
+    native.check("rt_rope_table", native.load().rt_rope_table(_dev(ids, "ids", F32), cos.data_ptr(), sin.data_ptr(), S, ax, float(theta), _stream()))
+    return cos, sin
+
+
+def layernorm_modulate(x: torch.Tensor, out: torch.Tensor, shift: Optional[torch.Tensor], scale: Optional[torch.Tensor],
+                       eps: float = 1e-6) -> torch.Tensor:
+    """x [B,R,D] (bf16|f32, unit inner stride) -> out [B,R,D] bf16 = LN(x)*(1+scale[b])+shift[b]; shift/scale f32 [B,D] views."""
+    if x.dim() != 3 or out.dim() != 3 or x.shape != out.shape or x.stride(2) != 1 or out.stride(2) != 1:
+        raise ValueError("layernorm_modulate: x/out must be [B,R,D] with unit inner stride")
+    B, R, D = x.shape
+    mod_ld = 0
+    if scale is not None:
+        if scale.shape != (B, D) or shift.shape != (B, D) or scale.stride(1) != 1 or shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("shift/scale must be [B,D] views with equal row stride")
+        mod_ld = scale.stride(0)
+    if x.dtype not in (BF16, F32):
+        raise TypeError("x must be bf16 or f32")
+    native.check("rt_layernorm_modulate", native.load().rt_layernorm_modulate(
+        _dev(x, "x"), x.stride(1), x.stride(0), int(x.dtype == F32), _dev(out, "out", BF16), out.stride(1), out.stride(0),
+        _opt(shift, "shift", F32), _opt(scale, "scale", F32), mod_ld, B, R, D, float(eps), _stream()))
+    return out
+
+
+def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_txt, wk_txt, wq_img, wk_img,
+                    cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6) -> None:
+    """In place on buf [B,S,ld] bf16: heads at columns q_off + h*128 / k_off + h*128."""
+    if buf.dim() != 3 or buf.stride(2) != 1:
+        raise ValueError("buf must be [B,S,ld] with unit inner stride")
+    B, S, _ = buf.shape
+    if cos.shape != (S, 128) or sin.shape != (S, 128) or not cos.is_contiguous() or not sin.is_contiguous():
+        raise ValueError("cos/sin must be contiguous [S,128]")
+    native.check("rt_qk_rmsnorm_rope", native.load().rt_qk_rmsnorm_rope(
+        _dev(buf, "buf", BF16), buf.stride(1), buf.stride(0), q_off, k_off, _opt(wq_txt, "wq_txt", BF16), _opt(wk_txt, "wk_txt", BF16),
+        _dev(wq_img, "wq_img", BF16), _dev(wk_img, "wk_img", BF16), _dev(cos, "cos", F32), _dev(sin, "sin", F32), B, S, T, H, float(eps), _stream()))
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q,k,v [B,S,H*128] views (common strides) of one buffer; out [B,S,H*128] view (may alias q)."""
+    for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        if t.dim() != 3 or t.stride(2) != 1 or t.shape[2] != H * 128:
+            raise ValueError(f"{name}: need [B,S,{H*128}] with unit inner stride")
+    B, S, _ = q.shape
+    if not (q.stride() == k.stride() == v.stride()) or k.shape != q.shape or v.shape != q.shape or out.shape != q.shape:
+        raise ValueError("q,k,v must share shape and strides")
+    sc = (128 ** -0.5) if scale is None else float(scale)
+    native.check("rt_attention_fwd", native.load().rt_attention_fwd(
+        _dev(q, "q", BF16), _dev(k, "k", BF16), _dev(v, "v", BF16), _dev(out, "out", BF16), q.stride(1), q.stride(0),
+        out.stride(1), out.stride(0), B, S, H, sc, _stream()))
+    return out
+
+
+def euler_step_(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> torch.Tensor:
+    if not (x.is_contiguous() and v.is_contiguous()) or x.shape != v.shape:
+        raise ValueError("euler_step_: contiguous tensors of equal shape")
+    native.check("rt_euler_step", native.load().rt_euler_step(_dev(x, "x", BF16), _dev(v, "v", BF16), float(dsigma), x.numel(), _stream()))
+    return x
+
+
+def cfg_mix(v_uncond: torch.Tensor, v_text: torch.Tensor, s: float) -> torch.Tensor:
+    out = torch.empty_like(v_text)
+    native.check("rt_cfg_mix", native.load().rt_cfg_mix(_dev(v_uncond.contiguous(), "u", BF16), _dev(v_text.contiguous(), "t", BF16), out.data_ptr(), float(s), out.numel(), _stream()))
+    return out
+
+
+def pack_latents(x: torch.Tensor) -> torch.Tensor:
+    B, Cc, H2, W2 = x.shape
+    x = x.contiguous()
+    out = torch.empty(B, (H2 // 2) * (W2 // 2), Cc * 4, device=x.device, dtype=BF16)
+    native.check("rt_pack_latents", native.load().rt_pack_latents(_dev(x, "x", BF16), out.data_ptr(), B, Cc, H2, W2, _stream()))
+    return out
+
+
+def unpack_latents_nhwc(packed: torch.Tensor, H2: int, W2: int, scaling: float, shift: float) -> torch.Tensor:
+    """[B,(H2/2)(W2/2),4C] -> NHWC [B,H2,W2,C] bf16 holding packed/scaling + shift."""
+    B, _, C4 = packed.shape
+    Cc = C4 // 4
+    packed = packed.contiguous()
+    out = torch.empty(B, H2, W2, Cc, device=packed.device, dtype=BF16)
+    native.check("rt_unpack_latents", native.load().rt_unpack_latents(_dev(packed, "packed", BF16), out.data_ptr(), B, Cc, H2, W2, 1.0 / float(scaling), float(shift), _stream()))
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    native.check("rt_cast_f32_to_bf16", native.load().rt_cast_f32_to_bf16(_dev(x, "x", F32), out.data_ptr(), x.numel(), _stream()))
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=F32)
+    native.check("rt_cast_bf16_to_f32", native.load().rt_cast_bf16_to_f32(_dev(x, "x", BF16), out.data_ptr(), x.numel(), _stream()))
+    return out
+
+
+def masked_accumulate_(y: torch.Tensor, x: torch.Tensor, rowscale: Optional[torch.Tensor], alpha: float = 1.0, accumulate: bool = True) -> torch.Tensor:
+    """y[b,r,:] (+)= alpha*rowscale[r]*x[b,r,:]; contiguous bf16 [B,R,D]."""
+    if x.shape != y.shape or x.dim() != 3 or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("masked_accumulate_: contiguous [B,R,D] tensors of equal shape")
+    B, R, D = x.shape
+    if rowscale is not None and (rowscale.numel() != R or not rowscale.is_contiguous()):
+        raise ValueError("rowscale must be contiguous with R elements")
+    native.check("rt_masked_accumulate", native.load().rt_masked_accumulate(
+        _dev(x, "x", BF16), _dev(y, "y", BF16), _opt(rowscale, "rowscale", F32), float(alpha), B, R, D, int(accumulate), _stream()))
+    return y

@@ -1,0 +1,161 @@
+/*
+ * reptext_hip.h — C ABI of librt_reptext_hip.so, the MI355X (gfx950) kernels behind the
+ * FLUX.1-dev + RepText-ControlNet denoising path and the AutoencoderKL decoder.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers and sizes only; no torch types cross this line.
+ *   - every pointer is a DEVICE pointer (HBM) unless its comment says "host".
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing here synchronises, allocates or frees (graph-capture safe).
+ *   - return value: 0 = enqueued; negative = argument rejected (RT_E_*), positive = hipError_t.
+ *   - bf16 tensors are raw uint16 bit patterns (torch.bfloat16 storage).
+ *
+ * Each entry replaces torch ops that the reference reaches through diffusers; the
+ * reference call site it serves is cited as file:line relative to /root/reference/RepText
+ * (CN = controlnet_flux.py, PIPE = pipeline_flux_controlnet.py, INP = ..._inpaint.py) and the
+ * third-party math as SURVEY.md Appendix A.x.
+ */
+#ifndef REPTEXT_HIP_H
+#define REPTEXT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_BADARG (-1)   /* null pointer / non-positive size */
+#define RT_E_ALIGN (-2)    /* pointer or leading dimension not aligned as documented */
+#define RT_E_SHAPE (-3)    /* shape outside what the kernel supports */
+
+/* Library identity: returns a static string "reptext_hip <abi> gfx950". */
+const char* rt_version(void);
+/* ABI revision; bumped when any struct below changes. */
+int rt_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear layers: C = epilogue(A · Wᵀ + bias), bf16 operands, fp32 accumulate on MFMA.
+ * Replaces every nn.Linear on the path: CN:277,280,292,386,391; Appendix A.1 steps 3,6,7,8;
+ * A.2 (proj_mlp, to_q/k/v fused, proj_out); A.3 (x_embedder, context_embedder, proj_out).
+ *
+ * Epilogue, applied per element (row m, column n) in this order:
+ *   v = acc + bias[n]
+ *   if n >= gelu_from:        v = gelu_tanh(v)                      (A.1 step 7 / A.2 act_mlp)
+ *   if gate:                  v *= gate[(m / rows_per_batch) * gate_ld + n]   (adaLN-Zero gates)
+ *   v *= alpha                                                      (CN:395 conditioning_scale)
+ *   if rowscale:              v *= rowscale[m % rows_per_batch]     (PIPE:1062 regional mask)
+ *   if res:                   v += res[m*ldr + n]                   (residual stream)
+ *   if add2:                  v += add2[m*ld2 + n]                  (A.3 ControlNet injection)
+ *   C[m*ldc + n] = v   (bf16, or fp32 when out_f32)
+ * `res`/`add2` may alias C. A group is one problem; up to RT_GEMM_MAX_GROUPS problems with the
+ * same K-loop code are tiled into ONE launch (image stream + text stream of a double block).
+ * Batched over `batch` with element strides (0 = shared).
+ * ---------------------------------------------------------------------------------------- */
+#define RT_GEMM_MAX_GROUPS 4
+
+typedef struct rt_gemm_group {
+  const void* A;        /* bf16 [batch][M][lda]          */
+  const void* W;        /* bf16 [N][ldw]  (torch Linear weight layout) */
+  void* C;              /* bf16|f32 [batch][M][ldc]       */
+  const void* bias;     /* bf16 [N] or NULL               */
+  const float* gate;    /* f32 [batch*..][gate_ld] or NULL */
+  const void* res;      /* same dtype as C, or NULL       */
+  const void* add2;     /* bf16 [batch][M][ld2] or NULL   */
+  const float* rowscale;/* f32 [rows_per_batch] or NULL   */
+  int64_t lda, ldw, ldc, ldr, ld2, gate_ld;
+  int64_t strideA, strideC, strideR, stride2;  /* per-batch element strides */
+  int32_t M, N, K;      /* K % 64 == 0, N % 4 == 0        */
+  int32_t batch;
+  int32_t rows_per_batch; /* rows sharing one gate vector; 0 => M */
+  int32_t gelu_from;    /* first column that gets GELU-tanh; >= N => none */
+  int32_t out_f32;      /* C/res dtype: 0 bf16, 1 f32     */
+  float alpha;
+} rt_gemm_group;
+
+int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
+
+/* Small-M linear on fp32 activations, bf16 weights (adaLN modulation, time/guidance/pooled MLPs):
+ *   y[b][n] (+)= post( Σ_k pre(x[b][k]) · W[n][k] + bias[n] ),  pre/post ∈ {identity, SiLU}
+ * Replaces AdaLayerNormZero/ZeroSingle/Continuous `linear(silu(temb))` (A.1 step 1, A.2, A.3) and
+ * CombinedTimestepGuidanceTextProjEmbeddings' MLPs (CN:287-291, A.5). HBM-bound on W. */
+int rt_gemv_bf16w(const float* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
+                  float* y, int64_t ldy, int32_t B, int32_t N, int32_t K,
+                  int32_t silu_in, int32_t silu_out, int32_t accumulate, void* stream);
+
+/* Timesteps(256, flip_sin_to_cos=True, shift 0): out[b] = [cos(t·f_j) | sin(t·f_j)], f_j = exp(-ln(1e4)·j/half).
+ * A.5; feeds CN:287-291. t is already multiplied by 1000 by the caller (CN:282-284). */
+int rt_timestep_embedding(const float* t, float* out, int32_t B, int32_t dim, void* stream);
+
+/* FluxPosEmbed (CN:65,316-317; A.5): ids f32 [S][3] -> cos,sin f32 [S][sum(axes_dim)], fp64 angles,
+ * each frequency repeated twice (interleaved). axes_dim host pointer, 3 ints. */
+int rt_rope_table(const float* ids, float* cos_out, float* sin_out, int32_t S,
+                  const int32_t* axes_dim /* host[3] */, float theta, void* stream);
+
+/* LayerNorm(no affine, eps) over the last dim then (1+scale)·x + shift with per-batch vectors.
+ * A.1 step 2/7/8, A.2, A.3 norm_out. x is bf16 or f32 (x_f32), out bf16.
+ * rows = batch*rows_per_batch rows of length D (D % 8 == 0, D <= 8192); row r of batch b reads
+ * x + b*stride_xb + r*ldx. shift/scale f32 with per-batch stride mod_ld (NULL => plain LN). */
+int rt_layernorm_modulate(const void* x, int64_t ldx, int64_t stride_xb, int32_t x_f32,
+                          void* out, int64_t ldo, int64_t stride_ob,
+                          const float* shift, const float* scale, int64_t mod_ld,
+                          int32_t batch, int32_t rows_per_batch, int32_t D, float eps, void* stream);
+
+/* RMSNorm(Dh, weight, eps) on q and k heads + interleaved-pair RoPE, in place on a fused
+ * projection buffer (A.1 steps 3,5; A.2). Row (b,s) holds q at column q_off and k at k_off,
+ * H heads of Dh=128 each. Rows s < T use the text weights (norm_added_q/k), others the image
+ * weights; pass T = 0 for single-stream blocks. cos/sin f32 [S][128]. */
+int rt_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t stride_b, int64_t q_off, int64_t k_off,
+                       const void* wq_txt, const void* wk_txt, const void* wq_img, const void* wk_img,
+                       const float* cosv, const float* sinv,
+                       int32_t B, int32_t S, int32_t T, int32_t H, float eps, void* stream);
+
+/* Joint (non-causal, unmasked) attention, softmax(QKᵀ·scale)V, Dh = 128, flash-style on MFMA
+ * (A.1 step 6; torch SDPA in the reference). q/k/v/o are bf16 with a common row stride ld
+ * (elements) and per-batch stride; head h lives at column h*128. o may alias q (each workgroup
+ * reads only the q rows it later overwrites). */
+int rt_attention_fwd(const void* q, const void* k, const void* v, void* o,
+                     int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
+                     int32_t B, int32_t S, int32_t H, float scale, void* stream);
+
+/* FlowMatchEulerDiscreteScheduler.step (PIPE:1109; A.6): x = bf16(f32(x) + dsigma·f32(v)), in place. */
+int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream);
+
+/* True-CFG mix of the inpaint pipeline (INP:1264-1270): out = uncond + s·(text − uncond); bf16. */
+int rt_cfg_mix(const void* v_uncond, const void* v_text, void* out, float s, int64_t n, void* stream);
+
+/* _pack_latents / _unpack_latents (PIPE:550-570): [B][C][2h][2w] <-> [B][h*w][4C], channel order (c,dy,dx).
+ * unpack also applies z/scaling + shift (PIPE:1137) and converts to NHWC bf16 for the decoder. */
+int rt_pack_latents(const void* nchw, void* packed, int32_t B, int32_t C, int32_t H2, int32_t W2, void* stream);
+int rt_unpack_latents(const void* packed, void* nchw, int32_t B, int32_t C, int32_t H2, int32_t W2,
+                      float inv_scale, float shift, void* stream);
+
+/* Elementwise helpers on the path. */
+int rt_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int rt_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* y[b][r][:] (+)= alpha · rowscale[r] · x[b][r][:]  — PIPE:1060-1087 masked sum over text lines (bf16). */
+int rt_masked_accumulate(const void* x, void* y, const float* rowscale, float alpha,
+                         int32_t batch, int32_t rows, int32_t D, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AutoencoderKL decoder (PIPE:1139; Appendix A.7). Activations are NHWC bf16.
+ * ---------------------------------------------------------------------------------------- */
+/* GroupNorm(G groups, eps, affine) + optional SiLU over NHWC; x may be upsampled 2x nearest on the fly
+ * by the consumer, not here. */
+int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta,
+                           int32_t B, int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, void* stream);
+/* 3x3 (or 1x1) convolution, stride 1, zero pad, as implicit GEMM on MFMA; optional nearest-2x upsample of the
+ * input fused into the gather; optional residual add. w is bf16 [Cout][ky][kx][Cin] (repacked from OIHW). */
+int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y,
+                   int32_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t ksize,
+                   int32_t upsample2x, int32_t out_f32, void* stream);
+/* Final image write: NHWC bf16/f32 [B][H][W][C<=4 padded] -> NCHW f32 [B][3][H][W]. */
+int rt_nhwc_to_nchw_f32(const void* x, int32_t x_f32, float* y, int32_t B, int32_t HW, int32_t Cpad, int32_t C, void* stream);
+/* Single-head attention for the VAE mid block (A.7): head dim Dh in {512}. q,k,v,o bf16 [B][S][Dh]. */
+int rt_attention_vae(const void* q, const void* k, const void* v, void* o,
+                     int64_t ld, int64_t ldo, int32_t B, int32_t S, int32_t Dh, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPTEXT_HIP_H */

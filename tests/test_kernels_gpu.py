@@ -1,0 +1,253 @@
+"""GPU parity: each HIP kernel (through the C ABI) vs the fp32 CPU oracle on the same seeded inputs.
+
+Tolerances are stated per test. bf16 has 8 significand bits (rel. rounding 2^-9 ≈ 2e-3); kernels accumulate
+and keep statistics in fp32, so the error budget is the bf16 rounding of inputs/outputs only.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_oracle as orc  # noqa: E402
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf16r(x):
+    """Round to bf16 and back: the oracle then sees exactly the values the GPU kernel reads."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture(scope="module")
+def ops(gpu):
+    import reptext_amd.ops as ops
+
+    return ops
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (300, 260, 128), (1024, 3072, 3072), (64, 64, 4096), (768, 21504, 3072)])
+def test_linear_bias(ops, gpu, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    b = bf16r(torch.randn(N, generator=g))
+    ref = torch.nn.functional.linear(a, w, b)
+    out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.linear(a.to(gpu, torch.bfloat16), w.to(gpu, torch.bfloat16), out, bias=b.to(gpu, torch.bfloat16))
+    # fp32 accumulate, one bf16 rounding of the output: rel-L2 ≤ 2^-9/sqrt(3)·~1.5
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    out32 = torch.empty(M, N, device=gpu, dtype=torch.float32)
+    ops.linear(a.to(gpu, torch.bfloat16), w.to(gpu, torch.bfloat16), out32, bias=b.to(gpu, torch.bfloat16))
+    assert rel_l2(out32.cpu(), ref) < 2e-5      # fp32 output: accumulation-order noise only
+
+
+def test_linear_identity_asymmetric(ops, gpu):
+    """A = I against an asymmetric W catches a transposed C write (guide §3)."""
+    n = 256
+    a = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 16.0   # exact in bf16? values k/16, k<251: yes
+    out = torch.empty(n, n, device=gpu, dtype=torch.float32)
+    ops.linear(a.to(gpu, torch.bfloat16), w.to(gpu, torch.bfloat16), out)
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+def test_linear_full_epilogue(ops, gpu):
+    """bias → GELU(cols ≥ gelu_from) → gate → alpha → rowscale → +res → +add2, batched rows (B=2)."""
+    B, R, N, K = 2, 320, 512, 256
+    M = B * R
+    g = torch.Generator().manual_seed(7)
+    a = bf16r(torch.randn(M, K, generator=g))
+    w = bf16r(torch.randn(N, K, generator=g) * 0.1)
+    bias = bf16r(torch.randn(N, generator=g))
+    gate = torch.randn(B, N, generator=g)
+    res = bf16r(torch.randn(M, N, generator=g))
+    add2 = bf16r(torch.randn(M, N, generator=g))
+    rowscale = torch.rand(R, generator=g)
+    gelu_from, alpha = 128, 0.75
+    v = torch.nn.functional.linear(a, w, bias)
+    v = torch.cat([v[:, :gelu_from], orc.gelu_tanh(v[:, gelu_from:])], dim=1)
+    v = v.view(B, R, N) * gate[:, None, :] * alpha * rowscale[None, :, None]
+    ref = v.reshape(M, N) + res + add2
+    dev = lambda t, dt=torch.bfloat16: t.to(gpu, dt)
+    out = dev(res).clone()                       # res aliases out (in-place residual update)
+    ops.linear(dev(a), dev(w), out, bias=dev(bias), gate=dev(gate, torch.float32), res=out, add2=dev(add2),
+               rowscale=dev(rowscale, torch.float32), rows_per_batch=R, gelu_from=gelu_from, alpha=alpha)
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    out32 = dev(res, torch.float32).clone()
+    ops.linear(dev(a), dev(w), out32, bias=dev(bias), gate=dev(gate, torch.float32), res=out32, add2=dev(add2),
+               rowscale=dev(rowscale, torch.float32), rows_per_batch=R, gelu_from=gelu_from, alpha=alpha)
+    assert rel_l2(out32.cpu(), ref) < 2e-5
+
+
+def test_linear_grouped_strided(ops, gpu):
+    """Two problems in one launch writing row ranges of one [B*S, 3d]-like buffer (text rows first), strided A."""
+    T, Nimg, d, K = 128, 384, 256, 192
+    S = T + Nimg
+    g = torch.Generator().manual_seed(11)
+    x = bf16r(torch.randn(S, K + 64, generator=g))          # lda > K
+    w_t = bf16r(torch.randn(3 * d, K, generator=g) * 0.1)
+    w_i = bf16r(torch.randn(3 * d, K, generator=g) * 0.1)
+    b_t = bf16r(torch.randn(3 * d, generator=g))
+    b_i = bf16r(torch.randn(3 * d, generator=g))
+    xd = x.to(gpu, torch.bfloat16)
+    out = torch.zeros(S, 3 * d + 128, device=gpu, dtype=torch.bfloat16)    # ldc > N
+    ops.linear_grouped([
+        ops.LinearProblem(xd[T:, :K], w_i.to(gpu, torch.bfloat16), out[T:, : 3 * d], bias=b_i.to(gpu, torch.bfloat16)),
+        ops.LinearProblem(xd[:T, :K], w_t.to(gpu, torch.bfloat16), out[:T, : 3 * d], bias=b_t.to(gpu, torch.bfloat16)),
+    ])
+    ref = torch.cat([torch.nn.functional.linear(x[:T, :K], w_t, b_t), torch.nn.functional.linear(x[T:, :K], w_i, b_i)])
+    assert rel_l2(out[:, : 3 * d].float().cpu(), ref) < 3e-3
+    assert float(out[:, 3 * d :].float().abs().max()) == 0.0   # padding columns untouched
+
+
+def test_linear_rejects_bad_args(ops, gpu):
+    from reptext_amd.native import NativeCallError
+
+    a = torch.zeros(64, 96, device=gpu, dtype=torch.bfloat16)      # K=96 not a multiple of 64
+    w = torch.zeros(64, 96, device=gpu, dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device=gpu, dtype=torch.bfloat16)
+    with pytest.raises(NativeCallError):
+        ops.linear(a, w, out)
+    with pytest.raises(RuntimeError):
+        ops.linear(a.cpu(), w, out)                                  # CPU tensor: error, never a fallback
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("D,xdtype", [(3072, torch.bfloat16), (3072, torch.float32), (512, torch.bfloat16), (4096, torch.bfloat16), (64, torch.float32)])
+def test_layernorm_modulate(ops, gpu, D, xdtype):
+    B, R = 2, 37
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(B, R, D, generator=g) * 3 + 0.5
+    if xdtype == torch.bfloat16:
+        x = bf16r(x)
+    shift, scale = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    ref = orc.layer_norm(x) * (1 + scale[:, None]) + shift[:, None]
+    mod = torch.cat([shift, scale], dim=1).to(gpu)                 # one [B, 2D] buffer, chunk views
+    out = torch.empty(B, R, D, device=gpu, dtype=torch.bfloat16)
+    ops.layernorm_modulate(x.to(gpu, xdtype), out, mod[:, :D], mod[:, D:])
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    out2 = torch.empty(B, R, D, device=gpu, dtype=torch.bfloat16)
+    ops.layernorm_modulate(x.to(gpu, xdtype), out2, None, None)
+    assert rel_l2(out2.float().cpu(), orc.layer_norm(x)) < 3e-3
+
+
+def test_qk_rmsnorm_rope(ops, gpu):
+    B, T, Nimg, H = 2, 24, 40, 3
+    S, d = T + Nimg, H * 128
+    g = torch.Generator().manual_seed(5)
+    buf = bf16r(torch.randn(B, S, 3 * d, generator=g))
+    ws = [bf16r(1 + 0.1 * torch.randn(128, generator=g)) for _ in range(4)]   # q_txt, k_txt, q_img, k_img
+    ids = torch.cat([torch.zeros(T, 3), orc.latent_image_ids(10, 16)], dim=0)
+    cos, sin = orc.rope_table(ids)
+    q, k = buf[..., :d].reshape(B, S, H, 128), buf[..., d : 2 * d].reshape(B, S, H, 128)
+    qn = torch.cat([orc.rms_norm(q[:, :T], ws[0]), orc.rms_norm(q[:, T:], ws[2])], dim=1)
+    kn = torch.cat([orc.rms_norm(k[:, :T], ws[1]), orc.rms_norm(k[:, T:], ws[3])], dim=1)
+    ref = buf.clone()
+    ref[..., :d] = orc.apply_rope(qn, cos, sin).reshape(B, S, d)
+    ref[..., d : 2 * d] = orc.apply_rope(kn, cos, sin).reshape(B, S, d)
+    dbuf = buf.to(gpu, torch.bfloat16)
+    wd = [w.to(gpu, torch.bfloat16) for w in ws]
+    ops.qk_rmsnorm_rope(dbuf, 0, d, H, T, wd[0], wd[1], wd[2], wd[3], cos.to(gpu), sin.to(gpu))
+    assert rel_l2(dbuf[..., : 2 * d].float().cpu(), ref[..., : 2 * d]) < 3e-3
+    assert torch.equal(dbuf[..., 2 * d :].float().cpu(), buf[..., 2 * d :])     # v untouched
+
+
+def test_rope_and_timestep_tables(ops, gpu):
+    ids = torch.cat([torch.zeros(16, 3), orc.latent_image_ids(128, 128)], dim=0)
+    cos, sin = ops.rope_table(ids.to(gpu))
+    rc, rs = orc.rope_table(ids)
+    assert float((cos.cpu() - rc).abs().max()) < 2e-6 and float((sin.cpu() - rs).abs().max()) < 2e-6
+    t = torch.tensor([1000.0, 622.459, 3500.0, 0.0])
+    emb = ops.timestep_embedding(t.to(gpu))
+    # fp32 sin/cos of arguments up to 3.5e3: device vs host libm differ by a few ulp of the ARGUMENT (~2e-4 abs)
+    assert float((emb.cpu() - orc.timestep_embedding(t)).abs().max()) < 5e-4
+
+
+def test_gemv(ops, gpu):
+    B, N, K = 3, 1000, 3072
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, K, generator=g)
+    w = bf16r(torch.randn(N, K, generator=g) * 0.02)
+    b = bf16r(torch.randn(N, generator=g))
+    y = torch.empty(B, N, device=gpu)
+    ops.gemv(x.to(gpu), w.to(gpu, torch.bfloat16), b.to(gpu, torch.bfloat16), y, silu_in=True)
+    ref = torch.nn.functional.linear(orc.silu(x), w, b)
+    assert rel_l2(y.cpu(), ref) < 1e-5
+    ops.gemv(x.to(gpu), w.to(gpu, torch.bfloat16), None, y, silu_out=True, accumulate=True)
+    ref2 = ref + orc.silu(torch.nn.functional.linear(x, w))
+    assert rel_l2(y.cpu(), ref2) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,S,H", [(1, 128, 1), (2, 768, 3), (1, 200, 2), (1, 4608, 2)])
+def test_attention(ops, gpu, B, S, H):
+    d = H * 128
+    g = torch.Generator().manual_seed(S)
+    qkv = bf16r(torch.randn(B, S, 3 * d, generator=g))
+    qkv[..., :d] *= 2.0                      # sharper softmax than N(0,1) scores
+    q, k, v = (qkv[..., i * d : (i + 1) * d].reshape(B, S, H, 128) for i in range(3))
+    ref = orc.attention(q, k, v)
+    dq = qkv.to(gpu, torch.bfloat16)
+    out = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
+    ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], out, H)
+    # P is rounded to bf16 before P·V and the output once more: ≈ 2·2^-9/sqrt(3)
+    assert rel_l2(out.float().cpu(), ref) < 5e-3
+    # in place over q
+    ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], dq[..., :d], H)
+    assert torch.equal(dq[..., :d], out)
+
+
+def test_attention_online_softmax_rescale(ops, gpu):
+    """Force the running-max rescale: one late key dominates one query row (guide §5.4 rule 26)."""
+    B, S, H = 1, 512, 1
+    g = torch.Generator().manual_seed(1)
+    q = bf16r(torch.randn(B, S, H, 128, generator=g))
+    k = bf16r(torch.randn(B, S, H, 128, generator=g))
+    v = bf16r(torch.randn(B, S, H, 128, generator=g))
+    k[0, 300, 0] = q[0, 17, 0] * 4.0          # score jumps by ~4·|q|²/sqrt(128) ≈ 45 at key tile 4
+    k[0, 450, 0] = q[0, 100, 0] * 6.0
+    k = bf16r(k)
+    ref = orc.attention(q, k, v)
+    dq, dk, dv = (t.reshape(B, S, 128).to(gpu, torch.bfloat16) for t in (q, k, v))
+    buf = torch.cat([dq, dk, dv], dim=-1).contiguous()
+    out = torch.empty(B, S, 128, device=gpu, dtype=torch.bfloat16)
+    ops.attention(buf[..., :128], buf[..., 128:256], buf[..., 256:], out, H)
+    assert rel_l2(out.float().cpu(), ref) < 5e-3
+    assert float((out.float().cpu()[0, 17] - ref[0, 17]).abs().max()) < 0.05
+
+
+# ------------------------------------------------------------------------------------------- elementwise
+def test_euler_pack_cast_mask(ops, gpu):
+    g = torch.Generator().manual_seed(2)
+    x = bf16r(torch.randn(2, 4096, 64, generator=g))
+    v = bf16r(torch.randn(2, 4096, 64, generator=g))
+    dx = x.to(gpu, torch.bfloat16)
+    ops.euler_step_(dx, v.to(gpu, torch.bfloat16), -0.0116)
+    ref = orc.euler_step(x.to(torch.bfloat16), v.to(torch.bfloat16), 1.0, 1.0 - 0.0116)
+    assert torch.equal(dx.cpu(), ref)         # fp32 axpy + one rounding: bit-exact
+
+    lat = bf16r(torch.randn(2, 16, 32, 48, generator=g))
+    packed = ops.pack_latents(lat.to(gpu, torch.bfloat16))
+    assert torch.equal(packed.float().cpu(), orc.pack_latents(lat))
+    nhwc = ops.unpack_latents_nhwc(packed, 32, 48, 0.3611, 0.1159)
+    ref_u = bf16r(orc.unpack_latents(orc.pack_latents(lat), 16 * 16, 24 * 16) / 0.3611 + 0.1159)
+    assert float((nhwc.float().cpu().permute(0, 3, 1, 2) - ref_u).abs().max()) <= 2 ** -6   # 1 bf16 ulp at |x|<4 (mul vs div)
+
+    f = torch.randn(1000, generator=g)
+    assert torch.equal(ops.to_bf16(f.to(gpu)).cpu(), f.to(torch.bfloat16))
+    assert torch.equal(ops.to_f32(f.to(gpu, torch.bfloat16)).cpu(), f.to(torch.bfloat16).float())
+
+    y = bf16r(torch.randn(2, 96, 256, generator=g))
+    xx = bf16r(torch.randn(2, 96, 256, generator=g))
+    mask = torch.rand(96, generator=g)
+    dy = y.to(gpu, torch.bfloat16)
+    ops.masked_accumulate_(dy, xx.to(gpu, torch.bfloat16), mask.to(gpu), alpha=0.5)
+    assert rel_l2(dy.float().cpu(), y + 0.5 * mask[None, :, None] * xx) < 3e-3
+    u = ops.cfg_mix(y.to(gpu, torch.bfloat16), xx.to(gpu, torch.bfloat16), 3.5)
+    assert rel_l2(u.float().cpu(), y + 3.5 * (xx - y)) < 3e-3

@@ -1,0 +1,80 @@
+"""Kernel micro-benchmarks at the C2 shapes (1024², S=4608, d=3072). Run on the GPU box:
+    python tools/bench_kernels.py [gemm|attn|all]
+Prints TFLOP/s from torch.cuda.Event timing on the current stream (same stream the kernels are enqueued on)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import reptext_amd.ops as ops
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def bench_gemm():
+    shapes = [(4608, 21504, 3072), (4608, 3072, 15360), (4096, 9216, 3072), (4096, 12288, 3072), (4096, 3072, 12288),
+              (4096, 3072, 3072), (512, 9216, 3072), (512, 12288, 3072), (8192, 8192, 8192)]
+    for M, N, K in shapes:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.linear(a, w, out, bias=b))
+        print(f"gemm M={M} N={N} K={K}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+    # grouped: image + text stream
+    T, Ni, d = 512, 4096, 3072
+    x = torch.randn(T + Ni, d, device=dev).to(torch.bfloat16)
+    wi = (torch.randn(3 * d, d, device=dev) * 0.02).to(torch.bfloat16)
+    wt = (torch.randn(3 * d, d, device=dev) * 0.02).to(torch.bfloat16)
+    out = torch.empty(T + Ni, 3 * d, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.linear_grouped([ops.LinearProblem(x[T:], wi, out[T:]), ops.LinearProblem(x[:T], wt, out[:T])]))
+    print(f"grouped qkv (4096+512)x9216x3072: {t*1e6:9.1f} us  {2*(T+Ni)*3*d*d/t/1e12:8.1f} TF/s", flush=True)
+
+
+def bench_attn():
+    for B, S, H in [(1, 4608, 24), (1, 768, 24), (1, 9728, 24)]:
+        d = H * 128
+        qkv = torch.randn(B, S, 3 * d, device=dev).to(torch.bfloat16)
+        out = torch.empty(B, S, d, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.attention(qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:], out, H))
+        print(f"attn B={B} S={S} H={H}: {t*1e6:9.1f} us  {4*B*H*S*S*128/t/1e12:8.1f} TF/s", flush=True)
+
+
+def bench_elem():
+    S, d = 4608, 3072
+    x = torch.randn(1, S, d, device=dev).to(torch.bfloat16)
+    out = torch.empty_like(x)
+    mod = torch.randn(1, 2 * d, device=dev)
+    t = timeit(lambda: ops.layernorm_modulate(x, out, mod[:, :d], mod[:, d:]))
+    print(f"layernorm_mod {S}x{d}: {t*1e6:8.1f} us  {2*S*d*2/t/1e9:8.1f} GB/s", flush=True)
+    w = (torch.randn(6 * d, d, device=dev) * 0.02).to(torch.bfloat16)
+    temb = torch.randn(1, d, device=dev)
+    y = torch.empty(1, 6 * d, device=dev)
+    t = timeit(lambda: ops.gemv(temb, w, None, y, silu_in=True))
+    print(f"adaLN gemv {6*d}x{d}: {t*1e6:8.1f} us  {6*d*d*2/t/1e9:8.1f} GB/s", flush=True)
+    qkv = torch.randn(1, S, 3 * d, device=dev).to(torch.bfloat16)
+    wn = torch.ones(128, device=dev, dtype=torch.bfloat16)
+    cos = torch.randn(S, 128, device=dev); sin = torch.randn(S, 128, device=dev)
+    t = timeit(lambda: ops.qk_rmsnorm_rope(qkv, 0, d, 24, 512, wn, wn, wn, wn, cos, sin))
+    print(f"qk_rmsnorm_rope {S}x{2*d}: {t*1e6:8.1f} us  {2*S*2*d*2/t/1e9:8.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("attn", "all"):
+        bench_attn()
+    if what in ("elem", "all"):
+        bench_elem()
