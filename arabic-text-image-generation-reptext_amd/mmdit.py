@@ -1,0 +1,195 @@
+"""Shared execution engine of the MMDiT stacks (FLUX transformer and ControlNet tower).
+
+Host side only: it sequences the HIP ops of ops.py over preallocated HBM buffers. Math per SURVEY.md
+Appendix A.1 (double-stream block), A.2 (single-stream block), A.5 (embeddings).
+
+HBM layout (B images, T text tokens, N image tokens, S = T+N, d = H·128), all bf16 unless noted:
+  x    [B,S,d]    residual stream, TEXT ROWS FIRST (the order attention concatenates them, A.1 step 4)
+  xn   [B,S,d]    LayerNorm+modulation output = A operand of the projections
+  qkv  [B,S,3d]   double blocks: [q|k|v]; attention output overwrites q in place
+  big  [B,S,7d]   single blocks: [k|v|q|mlp]; attention output overwrites q, so proj_out reads the
+                  contiguous [attn|mlp] = big[..., 2d:7d] with K = 5d — no concat, no copy
+  ffh  [B,S,4d]   double-block feed-forward hidden (image and text rows in one buffer)
+  mod  f32        adaLN vectors: [B,6d] per stream (double), [B,3d] (single)
+Image and text projections of a double block are issued as ONE grouped GEMM launch each.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import LinearProblem as P
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class DoublePlan:
+    ada_img_w: torch.Tensor
+    ada_img_b: torch.Tensor
+    ada_txt_w: torch.Tensor
+    ada_txt_b: torch.Tensor
+    qkv_img_w: torch.Tensor
+    qkv_img_b: torch.Tensor
+    qkv_txt_w: torch.Tensor
+    qkv_txt_b: torch.Tensor
+    nq_img: torch.Tensor
+    nk_img: torch.Tensor
+    nq_txt: torch.Tensor
+    nk_txt: torch.Tensor
+    out_img_w: torch.Tensor
+    out_img_b: torch.Tensor
+    out_txt_w: torch.Tensor
+    out_txt_b: torch.Tensor
+    ff1_img_w: torch.Tensor
+    ff1_img_b: torch.Tensor
+    ff2_img_w: torch.Tensor
+    ff2_img_b: torch.Tensor
+    ff1_txt_w: torch.Tensor
+    ff1_txt_b: torch.Tensor
+    ff2_txt_w: torch.Tensor
+    ff2_txt_b: torch.Tensor
+
+
+@dataclass
+class SinglePlan:
+    ada_w: torch.Tensor
+    ada_b: torch.Tensor
+    fused_w: torch.Tensor   # rows: [to_k | to_v | to_q | proj_mlp]
+    fused_b: torch.Tensor
+    nq: torch.Tensor
+    nk: torch.Tensor
+    out_w: torch.Tensor
+    out_b: torch.Tensor
+
+
+def _fuse(lins) -> tuple:
+    """Concatenate Linear weights/biases along the output dim and re-point the originals at views of the fused
+    storage, so the separate copies are freed and later in-place loads (load_state_dict) stay fused."""
+    w = torch.cat([l.weight.data for l in lins], dim=0).contiguous()
+    b = torch.cat([l.bias.data for l in lins], dim=0).contiguous()
+    o = 0
+    for l in lins:
+        n = l.weight.shape[0]
+        l.weight.data = w[o : o + n]
+        l.bias.data = b[o : o + n]
+        o += n
+    return w, b
+
+
+def plan_double(blk) -> DoublePlan:
+    a = blk.attn
+    qi_w, qi_b = _fuse([a.to_q, a.to_k, a.to_v])
+    qt_w, qt_b = _fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
+    return DoublePlan(
+        blk.norm1.linear.weight.data, blk.norm1.linear.bias.data, blk.norm1_context.linear.weight.data,
+        blk.norm1_context.linear.bias.data, qi_w, qi_b, qt_w, qt_b, a.norm_q.weight.data, a.norm_k.weight.data,
+        a.norm_added_q.weight.data, a.norm_added_k.weight.data, a.to_out[0].weight.data, a.to_out[0].bias.data,
+        a.to_add_out.weight.data, a.to_add_out.bias.data, blk.ff.net[0].proj.weight.data, blk.ff.net[0].proj.bias.data,
+        blk.ff.net[2].weight.data, blk.ff.net[2].bias.data, blk.ff_context.net[0].proj.weight.data,
+        blk.ff_context.net[0].proj.bias.data, blk.ff_context.net[2].weight.data, blk.ff_context.net[2].bias.data)
+
+
+def plan_single(blk) -> SinglePlan:
+    a = blk.attn
+    fw, fb = _fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])
+    return SinglePlan(blk.norm.linear.weight.data, blk.norm.linear.bias.data, fw, fb, a.norm_q.weight.data,
+                      a.norm_k.weight.data, blk.proj_out.weight.data, blk.proj_out.bias.data)
+
+
+class Workspace:
+    """Preallocated activations for one (B,T,N) shape; reused across blocks, steps and models on the same device."""
+
+    def __init__(self, B: int, T: int, N: int, d: int, device, need_single: bool):
+        S = T + N
+        self.B, self.T, self.N, self.S, self.d = B, T, N, S, d
+        e = lambda *shape, dt=BF16: torch.empty(*shape, device=device, dtype=dt)
+        self.x = e(B, S, d)
+        self.xn = e(B, S, d)
+        self.qkv = e(B, S, 3 * d)
+        self.ffh = e(B, S, 4 * d)
+        self.big = e(B, S, 7 * d) if need_single else None
+        self.mod_a = e(B, 6 * d, dt=F32)
+        self.mod_b = e(B, 6 * d, dt=F32)
+        self.temb = e(B, d, dt=F32)
+        self.tmp = e(B, d, dt=F32)
+
+
+_WS_CACHE = {}
+
+
+def workspace(B, T, N, d, device, need_single) -> Workspace:
+    key = (B, T, N, d, str(device))
+    ws = _WS_CACHE.get(key)
+    if ws is None or (need_single and ws.big is None):
+        if len(_WS_CACHE) > 4:
+            _WS_CACHE.clear()
+        ws = Workspace(B, T, N, d, device, need_single)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def time_text_embed(tte, ws: Workspace, t1000: torch.Tensor, g1000: Optional[torch.Tensor], pooled: torch.Tensor) -> torch.Tensor:
+    """temb = MLP(sinusoid(t)) [+ MLP(sinusoid(g))] + MLP(pooled), fp32 [B,d] (A.5; CN:287-291)."""
+    def mlp(m, x_f32, accumulate):
+        ops.gemv(x_f32, m.linear_1.weight.data, m.linear_1.bias.data, ws.tmp, silu_out=True)
+        ops.gemv(ws.tmp, m.linear_2.weight.data, m.linear_2.bias.data, ws.temb, accumulate=accumulate)
+
+    mlp(tte.timestep_embedder, ops.timestep_embedding(t1000, 256), False)
+    if g1000 is not None:
+        mlp(tte.guidance_embedder, ops.timestep_embedding(g1000, 256), True)
+    pooled_f32 = pooled if pooled.dtype == F32 else ops.to_f32(pooled)
+    mlp(tte.text_embedder, pooled_f32.contiguous(), True)
+    return ws.temb
+
+
+def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None) -> None:
+    """One FluxTransformerBlock on ws.x in place (A.1). ``inject`` [B,N,d] bf16 is added to the image rows after the
+    block (A.3 ControlNet residual), fused into the last GEMM's epilogue."""
+    T, d = ws.T, ws.d
+    x_t, x_i = ws.x[:, :T], ws.x[:, T:]
+    xn_t, xn_i = ws.xn[:, :T], ws.xn[:, T:]
+    mi, mt = ws.mod_a, ws.mod_b
+    # 1. adaLN-Zero vectors: chunk order shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    ops.gemv(temb, pl.ada_img_w, pl.ada_img_b, mi, silu_in=True)
+    ops.gemv(temb, pl.ada_txt_w, pl.ada_txt_b, mt, silu_in=True)
+    ch = lambda m, i: m[:, i * d : (i + 1) * d]
+    # 2. norm + modulate
+    ops.layernorm_modulate(x_i, xn_i, ch(mi, 0), ch(mi, 1))
+    ops.layernorm_modulate(x_t, xn_t, ch(mt, 0), ch(mt, 1))
+    # 3. q,k,v projections of both streams, one launch
+    ops.linear_grouped([P(xn_i, pl.qkv_img_w, ws.qkv[:, T:], bias=pl.qkv_img_b), P(xn_t, pl.qkv_txt_w, ws.qkv[:, :T], bias=pl.qkv_txt_b)])
+    # 4.-5. RMSNorm(q,k) + RoPE in place
+    ops.qk_rmsnorm_rope(ws.qkv, 0, d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin)
+    # 6. joint attention; output over q
+    q, k, v = ws.qkv[..., :d], ws.qkv[..., d : 2 * d], ws.qkv[..., 2 * d :]
+    ops.attention(q, k, v, q, H)
+    # 7./8. x += gate_msa * out_proj(attn)
+    ops.linear_grouped([P(q[:, T:], pl.out_img_w, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i),
+                        P(q[:, :T], pl.out_txt_w, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t)])
+    ops.layernorm_modulate(x_i, xn_i, ch(mi, 3), ch(mi, 4))
+    ops.layernorm_modulate(x_t, xn_t, ch(mt, 3), ch(mt, 4))
+    ops.linear_grouped([P(xn_i, pl.ff1_img_w, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0),
+                        P(xn_t, pl.ff1_txt_w, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0)])
+    ops.linear_grouped([P(ws.ffh[:, T:], pl.ff2_img_w, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject),
+                        P(ws.ffh[:, :T], pl.ff2_txt_w, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t)])
+
+
+def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None) -> None:
+    """One FluxSingleTransformerBlock on ws.x in place (A.2)."""
+    T, d = ws.T, ws.d
+    m = ws.mod_a[:, : 3 * d]
+    ops.gemv(temb, pl.ada_w, pl.ada_b, m, silu_in=True)                       # shift, scale, gate
+    ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
+    big = ws.big
+    ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)        # [k|v|q|gelu(mlp)]
+    ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
+    q = big[..., 2 * d : 3 * d]
+    ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)
+    ops.linear(big[..., 2 * d :], pl.out_w, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x)
+    if inject is not None:                                                       # A.3: image tokens only
+        for b in range(ws.B):   # image rows of one batch entry are contiguous; one call per image
+            ops.masked_accumulate_(ws.x[b, T:].unsqueeze(0), inject[b : b + 1].contiguous(), None, 1.0, True)

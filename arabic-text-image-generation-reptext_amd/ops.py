@@ -42,12 +42,24 @@ def _rowmajor2d(t: torch.Tensor, name: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+def _batched(t: torch.Tensor, name: str):
+    """(batch, rows, cols, ld, batch_stride) of a [R,C] or [B,R,C] view with unit inner stride."""
+    if t.dim() == 2:
+        r, c, ld = _rowmajor2d(t, name)
+        return 1, r, c, ld, 0
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError(f"{name}: need [R,C] or [B,R,C] with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    return t.shape[0], t.shape[1], t.shape[2], t.stride(1), t.stride(0)
+
+
 @dataclass
 class LinearProblem:
-    """One group of rt_gemm_bf16: out = epilogue(a @ w.T + bias). 2-D row-major views (unit inner stride).
+    """One group of rt_gemm_bf16: out = epilogue(a @ w.T + bias).
 
-    a [M,K] bf16, w [N,K] bf16, out [M,N] bf16|f32. gate f32 [M/rows_per_batch, >=N]; res same dtype/shape as
-    out (may alias); add2 bf16 [M,N]; rowscale f32 [rows_per_batch]."""
+    a [M,K] or [B,M,K] bf16 views (unit inner stride); w [N,K] bf16; out [.., M, N] bf16|f32.
+    gate f32: [B,N] view (one vector per batch) — or, for 2-D problems whose rows are batch-major,
+    [M/rows_per_batch, N] with rows_per_batch set. res same dtype/shape as out (may alias it);
+    add2 bf16 same shape; rowscale f32 [rows_per_batch or M]."""
 
     a: torch.Tensor
     w: torch.Tensor
@@ -62,10 +74,10 @@ class LinearProblem:
     alpha: float = 1.0
 
     def to_group(self) -> native.GemmGroup:
-        M, K, lda = _rowmajor2d(self.a, "a")
+        Bt, M, K, lda, sA = _batched(self.a, "a")
         N, Kw, ldw = _rowmajor2d(self.w, "w")
-        Mo, No, ldc = _rowmajor2d(self.out, "out")
-        if Kw != K or Mo != M or No != N:
+        Bo, Mo, No, ldc, sC = _batched(self.out, "out")
+        if Kw != K or Mo != M or No != N or Bo != Bt:
             raise ValueError(f"linear shapes mismatch: a{tuple(self.a.shape)} w{tuple(self.w.shape)} out{tuple(self.out.shape)}")
         g = native.GemmGroup()
         g.A = _dev(self.a, "a", BF16)
@@ -75,34 +87,34 @@ class LinearProblem:
         g.C = _dev(self.out, "out")
         g.out_f32 = 1 if self.out.dtype == F32 else 0
         g.lda, g.ldw, g.ldc = lda, ldw, ldc
-        g.M, g.N, g.K, g.batch = M, N, K, 1
+        g.strideA, g.strideC = sA, sC
+        g.M, g.N, g.K, g.batch = M, N, K, Bt
         g.bias = _opt(self.bias, "bias", BF16)
         if self.bias is not None and self.bias.numel() != N:
             raise ValueError("bias length != N")
         rpb = self.rows_per_batch
+        rows = rpb if rpb > 0 else M
         if self.gate is not None:
             gr, gc, gld = _rowmajor2d(self.gate, "gate")
-            rows = rpb if rpb > 0 else M
-            if gc < N or gr * rows < M:
+            if gc < N or gr < Bt * (M // rows):
                 raise ValueError("gate too small for this problem")
             g.gate = _dev(self.gate, "gate", F32)
             g.gate_ld = gld
         if self.res is not None:
-            rr, rc, ldr = _rowmajor2d(self.res, "res")
-            if (rr, rc) != (M, N) or self.res.dtype != self.out.dtype:
+            Br, rr, rc, ldr, sR = _batched(self.res, "res")
+            if (Br, rr, rc) != (Bt, M, N) or self.res.dtype != self.out.dtype:
                 raise ValueError("res must match out in shape and dtype")
             g.res = _dev(self.res, "res")
-            g.ldr = ldr
+            g.ldr, g.strideR = ldr, sR
         if self.add2 is not None:
-            ar, ac, ld2 = _rowmajor2d(self.add2, "add2")
-            if (ar, ac) != (M, N):
-                raise ValueError("add2 must be [M,N]")
+            B2, ar, ac, ld2, s2 = _batched(self.add2, "add2")
+            if (B2, ar, ac) != (Bt, M, N):
+                raise ValueError("add2 must match out in shape")
             g.add2 = _dev(self.add2, "add2", BF16)
-            g.ld2 = ld2
+            g.ld2, g.stride2 = ld2, s2
         if self.rowscale is not None:
-            rows = rpb if rpb > 0 else M
             if self.rowscale.numel() != rows or not self.rowscale.is_contiguous():
-                raise ValueError("rowscale must be contiguous with rows_per_batch elements")
+                raise ValueError("rowscale must be contiguous with rows_per_batch (or M) elements")
             g.rowscale = _dev(self.rowscale, "rowscale", F32)
         g.rows_per_batch = rpb
         g.gelu_from = N if self.gelu_from is None else int(self.gelu_from)

@@ -1,0 +1,189 @@
+"""FluxTransformer2DModel — the denoiser the reference imports from diffusers (PIPE:31) and calls at PIPE:1092-1104.
+
+Not present under /root/reference; behaviour per SURVEY.md Appendix A.3. Same constructor config keys, same
+``forward`` keyword names and return convention (``(sample,)`` when ``return_dict=False``), HIP kernels underneath.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import mmdit, ops
+from .config import Config, flux_dev_transformer_config
+from .modules import DoubleBlockParams, Lin, SingleBlockParams, TimeTextEmbedParams, WeightsIO, _ada
+from .ops import LinearProblem as P
+
+
+@dataclass
+class Transformer2DModelOutput:
+    sample: torch.Tensor
+
+
+class _MMDiTBase(nn.Module, WeightsIO):
+    """Construction, planning and embedding steps common to the transformer and the ControlNet tower."""
+
+    def _build_trunk(self, cfg: Config, device, dtype):
+        kw = dict(device=device, dtype=dtype)
+        d = cfg.num_attention_heads * cfg.attention_head_dim
+        if cfg.attention_head_dim != 128:
+            raise ValueError("the HIP attention kernels are specialised for attention_head_dim == 128")
+        if sum(cfg.axes_dims_rope) != cfg.attention_head_dim:
+            raise ValueError("sum(axes_dims_rope) must equal attention_head_dim")
+        self.inner_dim = d
+        self.time_text_embed = TimeTextEmbedParams(d, cfg.pooled_projection_dim, bool(cfg.guidance_embeds), **kw)
+        self.context_embedder = Lin(cfg.joint_attention_dim, d, **kw)
+        self.x_embedder = Lin(cfg.in_channels, d, **kw)
+        self.transformer_blocks = nn.ModuleList([DoubleBlockParams(d, cfg.attention_head_dim, **kw) for _ in range(cfg.num_layers)])
+        self.single_transformer_blocks = nn.ModuleList([SingleBlockParams(d, cfg.attention_head_dim, **kw) for _ in range(cfg.num_single_layers)])
+        self._plans = None
+        self._plan_key = None
+        self._rope_cache = {}
+
+    # ---- properties the pipelines read (PIPE:906)
+    @property
+    def dtype(self):
+        return self.x_embedder.weight.dtype
+
+    @property
+    def device(self):
+        return self.x_embedder.weight.device
+
+    def random_init_(self, seed: int = 0, std: float = 0.02, bias_std: float = 0.02):
+        """Synthetic weights for benchmarks (no checkpoints offline): W ~ N(0, std²), small biases, norm weights ≈ 1."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_added_q.weight") or name.endswith("norm_added_k.weight"):
+                p.data.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32))
+            elif name.endswith(".bias"):
+                p.data.copy_(bias_std * torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32))
+            else:
+                p.data.copy_(std * torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32))
+        self._plans = None
+        return self
+
+    def _ensure_plans(self):
+        """(Re)build fused weight views when parameters moved (``.to``) or were never planned."""
+        key = (self.x_embedder.weight.data_ptr(), str(self.device), self.dtype)
+        if self._plans is not None and self._plan_key == key:
+            return self._plans
+        if self.dtype != torch.bfloat16:
+            raise TypeError(f"{type(self).__name__}: HIP path computes in bf16 storage; got {self.dtype}. Use torch_dtype=torch.bfloat16.")
+        if not self.x_embedder.weight.is_cuda:
+            raise RuntimeError(f"{type(self).__name__} is on {self.device}; move it to the GPU (.to('cuda')). There is no CPU fallback.")
+        self._plans = ([mmdit.plan_double(b) for b in self.transformer_blocks], [mmdit.plan_single(b) for b in self.single_transformer_blocks])
+        self._plan_key = key
+        self._rope_cache = {}
+        return self._plans
+
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, sd, strict: bool = True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        return out
+
+    def _rope(self, txt_ids: torch.Tensor, img_ids: torch.Tensor):
+        """cos/sin [S,128] fp32; constant over the denoising loop, so cached on the id tensors' identity."""
+        if txt_ids.dim() == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.dim() == 3:
+            img_ids = img_ids[0]
+        key = (txt_ids.data_ptr(), img_ids.data_ptr(), txt_ids.shape[0], img_ids.shape[0])
+        hit = self._rope_cache.get(key)
+        if hit is None:
+            ids = torch.cat([txt_ids.to(torch.float32), img_ids.to(torch.float32)], dim=0)
+            hit = ops.rope_table(ids, tuple(self.config.axes_dims_rope), 10000.0)
+            if len(self._rope_cache) > 8:
+                self._rope_cache.clear()
+            self._rope_cache[key] = hit + (txt_ids, img_ids)   # keep the id tensors alive so data_ptr stays unique
+        return hit[0], hit[1]
+
+    def _temb(self, ws, timestep, guidance, pooled):
+        t1000 = timestep.to(torch.float32).reshape(-1) * 1000.0
+        if t1000.numel() == 1 and ws.B > 1:
+            t1000 = t1000.expand(ws.B)
+        g1000 = None
+        if self.config.guidance_embeds:
+            if guidance is None:
+                raise ValueError("guidance_embeds=True requires `guidance`")
+            g1000 = (guidance.to(torch.float32).reshape(-1) * 1000.0).contiguous()
+            if g1000.numel() == 1 and ws.B > 1:
+                g1000 = g1000.expand(ws.B).contiguous()
+        return mmdit.time_text_embed(self.time_text_embed, ws, t1000.contiguous(), g1000, pooled)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, subfolder: Optional[str] = None, device=None, **unused):
+        d = cls._resolve_dir(path, subfolder)
+        cfg = Config.from_json_file(d + "/" + cls.config_name)
+        model = cls(**cfg, device=device or "cpu", dtype=torch_dtype or torch.bfloat16)
+        sd = cls._load_safetensors_dir(d)
+        model.load_state_dict({k: v.to(torch_dtype or torch.bfloat16) for k, v in sd.items()}, strict=True)
+        return model
+
+
+class FluxTransformer2DModel(_MMDiTBase):
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, out_channels: Optional[int] = None, num_layers: int = 19,
+                 num_single_layers: int = 38, attention_head_dim: int = 128, num_attention_heads: int = 24,
+                 joint_attention_dim: int = 4096, pooled_projection_dim: int = 768, guidance_embeds: bool = False,
+                 axes_dims_rope=(16, 56, 56), device=None, dtype=None):
+        super().__init__()
+        self.config = Config(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels, num_layers=num_layers,
+                             num_single_layers=num_single_layers, attention_head_dim=attention_head_dim,
+                             num_attention_heads=num_attention_heads, joint_attention_dim=joint_attention_dim,
+                             pooled_projection_dim=pooled_projection_dim, guidance_embeds=guidance_embeds,
+                             axes_dims_rope=list(axes_dims_rope))
+        self.out_channels = out_channels or in_channels
+        self._build_trunk(self.config, device, dtype)
+        d = self.inner_dim
+        self.norm_out = _ada(d, 2, device=device, dtype=dtype)
+        self.proj_out = Lin(d, patch_size * patch_size * self.out_channels, device=device, dtype=dtype)
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, img_ids: torch.Tensor = None,
+                txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
+                joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
+                controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False):
+        doubles, singles = self._ensure_plans()
+        cfg = self.config
+        B, N, _ = hidden_states.shape
+        Bc = encoder_hidden_states.shape[0]       # conditioning batch may be a multiple of B (inpaint CFG, Q6)
+        T = encoder_hidden_states.shape[1]
+        H, d = cfg.num_attention_heads, self.inner_dim
+        ws = mmdit.workspace(Bc, T, N, d, hidden_states.device, need_single=len(singles) > 0)
+        hs = hidden_states.to(torch.bfloat16)
+        if Bc != B:
+            if Bc % B:
+                raise ValueError("conditioning batch must be a multiple of the latent batch")
+            hs = hs.repeat(Bc // B, 1, 1)
+        ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, ws.x[:, T:], bias=self.x_embedder.bias.data),
+                            P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, ws.x[:, :T],
+                              bias=self.context_embedder.bias.data)])
+        temb = self._temb(ws, timestep, guidance, pooled_projections)
+        cos, sin = self._rope(txt_ids, img_ids)
+        nl, ns = len(doubles), len(singles)
+        for i, pl in enumerate(doubles):
+            inj = None
+            if controlnet_block_samples is not None:
+                ns_c = len(controlnet_block_samples)
+                inj = controlnet_block_samples[i % ns_c] if controlnet_blocks_repeat else controlnet_block_samples[i // int(math.ceil(nl / ns_c))]
+            mmdit.run_double(pl, ws, temb, cos, sin, H, inject=inj)
+        for i, pl in enumerate(singles):
+            inj = None
+            if controlnet_single_block_samples is not None:
+                inj = controlnet_single_block_samples[i // int(math.ceil(ns / len(controlnet_single_block_samples)))]
+            mmdit.run_single(pl, ws, temb, cos, sin, H, inject=inj)
+        # AdaLayerNormContinuous: chunk order (scale, shift)  — A.3
+        m = ws.mod_a[:, : 2 * d]
+        ops.gemv(temb, self.norm_out.linear.weight.data, self.norm_out.linear.bias.data, m, silu_in=True)
+        ops.layernorm_modulate(ws.x[:, T:], ws.xn[:, T:], m[:, d : 2 * d], m[:, :d])
+        out = torch.empty(Bc, N, self.proj_out.weight.shape[0], device=hs.device, dtype=torch.bfloat16)
+        ops.linear(ws.xn[:, T:], self.proj_out.weight.data, out, bias=self.proj_out.bias.data)
+        if not return_dict:
+            return (out,)
+        return Transformer2DModelOutput(sample=out)
