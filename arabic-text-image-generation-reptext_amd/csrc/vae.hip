@@ -1,0 +1,469 @@
+// AutoencoderKL kernels (FLUX VAE): implicit-GEMM convolution on MFMA, GroupNorm(+SiLU), row softmax and
+// transpose for the mid-block attention, image post-processing. Math: SURVEY.md Appendix A.7 (diffusers
+// AutoencoderKL, not present under /root/reference); call sites PIPE:467,705,711 (encode) and PIPE:1139 (decode).
+//
+// Activation layout in HBM: zero-haloed NHWC bf16, [B][H+2][W+2][C]. The 1-pixel halo is allocated zeroed and
+// never written, so the 3×3 gather needs no bounds checks and LDS-DMA can fetch every tap directly:
+//   stride 1 : source (y+dy-1, x+dx-1)            -> halo index +1
+//   nearest-2x upsample fused: source floor((y+dy-1)/2)  (so Up = gather, no 4x tensor is ever written)
+//   stride 2, pad (0,1,0,1) (encoder Downsample)  : source (2y+dy, 2x+dx)
+// The GEMM is M = B·Ho·Wo output pixels, N = Cout, K = taps·Cin with the same 256×256×64 tiling, LDS image and
+// swizzle as gemm_bf16.hip; a K-tile is 64 channels of one tap, so its A rows are 128-B runs of the input.
+#include "rt_common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int THREADS = 512;
+constexpr int TILE_BYTES = BM * BK * 2;
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+constexpr int LDS_BYTES = 2 * BUF_BYTES;
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const bf16_t* bias;
+  const bf16_t* res;
+  void* y;
+  int B, Hs, Ws, Ho, Wo, Cin, Cout, ks, stride, ups, out_f32;
+};
+
+__global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = (a.B * a.Ho * a.Wo + BM - 1) / BM;
+  const int tn = blockIdx.x / tiles_m;
+  const int tm = blockIdx.x - tn * tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = a.B * a.Ho * a.Wo;
+  const int K = a.ks * a.ks * a.Cin;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int pad = a.ks >> 1;
+  const int Wp = a.Ws + 2;
+
+  // staging: this lane's 4 output pixels (one per piece) and weight rows
+  int pb[4], py[4], px[4], plc[4];
+  const bf16_t* srcW[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = wave * 32 + p * 8 + (lane >> 3);
+    plc[p] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    const int m = min(m0 + row, M - 1);
+    const int b = m / (a.Ho * a.Wo);
+    const int r = m - b * a.Ho * a.Wo;
+    pb[p] = b; py[p] = r / a.Wo; px[p] = r - py[p] * a.Wo;
+    const int wr = min(n0 + row, a.Cout - 1);
+    srcW[p] = a.w + (int64_t)wr * K + plc[p];
+  }
+  const int stage_off = wave * 32 * 128;
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * BUF_BYTES + stage_off;
+    const int k0 = kt * BK;
+    const int tap = k0 / a.Cin;                 // wave-uniform
+    const int c0 = k0 - tap * a.Cin;
+    const int dy = tap / a.ks, dx = tap - dy * a.ks;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int sy, sx;
+      if (a.stride == 2) { sy = 2 * py[p] + dy + 1; sx = 2 * px[p] + dx + 1; }
+      else { sy = ((py[p] + dy - pad) >> a.ups) + 1; sx = ((px[p] + dx - pad) >> a.ups) + 1; }
+      const bf16_t* src = a.x + (((int64_t)pb[p] * (a.Hs + 2) + sy) * Wp + sx) * a.Cin + c0 + plc[p];
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + p * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(srcW[p] + k0), LDS_PTR(base + TILE_BYTES + p * 1024), 16, 0, 0);
+    }
+  };
+
+  const int l15 = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
+  const int a_base = wm * 128 * 128;
+  const int w_base = TILE_BYTES + wn * 64 * 128;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // waves whose 64 output columns are all >= Cout still stage (they share the tile) but skip the MFMAs
+  const bool wave_live = (n0 + wn * 64) < a.Cout;
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* tb = smem + cur * BUF_BYTES;
+    if (wave_live) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int rd = kk ? rd1 : rd0;
+        bf16x8 wf[4], af[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(tb + w_base + j * 2048 + rd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tb + a_base + i * 2048 + rd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!wave_live) return;
+  const int mrow = m0 + wm * 128 + l15;
+  const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = mrow + i * 16;
+    if (m >= M) continue;
+    const int b = m / (a.Ho * a.Wo);
+    const int r = m - b * a.Ho * a.Wo;
+    const int oy = r / a.Wo, ox = r - oy * a.Wo;
+    const int64_t pix = (((int64_t)b * (a.Ho + 2) + oy + 1) * (a.Wo + 2) + ox + 1) * a.Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol + j * 16;
+      if (n >= a.Cout) continue;
+      f32x4 v = acc[i][j];
+      if (a.bias) {
+        const u32x2 bb = *reinterpret_cast<const u32x2*>(a.bias + n);
+        v[0] += bf16lo(bb[0]); v[1] += bf16hi(bb[0]); v[2] += bf16lo(bb[1]); v[3] += bf16hi(bb[1]);
+      }
+      if (a.res) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(a.res + pix + n);
+        v[0] += bf16lo(rr[0]); v[1] += bf16hi(rr[0]); v[2] += bf16lo(rr[1]); v[3] += bf16hi(rr[1]);
+      }
+      if (a.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix + n) = v;
+      } else {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.y) + pix + n) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm over haloed NHWC. Pass 1: per-(b,group) sum / sum of squares (fp32 per thread, fp64 atomics).
+// Pass 2: normalise, affine, optional SiLU, write the interior of a haloed buffer.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats, int B,
+                                                        int H, int W, int C, int G, int pix_per_block) {
+  // thread t handles channel chunk (t % (C/8)) of pixels t / (C/8) + k*(256/(C/8))
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);            // [G][2]
+  const int c8 = C / 8;
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const int cpg = C / G;                                  // channels per group
+  const int p0 = blockIdx.x * pix_per_block;
+  const int pend = min(p0 + pix_per_block, H * W);
+  const int chunk = threadIdx.x % c8;
+  const int pstep = blockDim.x / c8;
+  float se[8], qe[8];                                      // one partial per element of this thread's 8-channel chunk
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { se[i] = 0.f; qe[i] = 0.f; }
+  for (int p = p0 + threadIdx.x / c8; p < pend; p += pstep) {
+    const int yy = p / W, xx = p - yy * W;
+    const u32x4 u = *reinterpret_cast<const u32x4*>(x + (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + chunk * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a0 = bf16lo(u[i]), a1 = bf16hi(u[i]);
+      se[2 * i] += a0; qe[2 * i] += a0 * a0;
+      se[2 * i + 1] += a1; qe[2 * i + 1] += a1 * a1;
+    }
+  }
+  // fold the 8 element partials into their groups (any channels-per-group), then one LDS atomic per group touched
+  float gs = 0.f, gq = 0.f;
+  int gcur = (chunk * 8) / cpg;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int gi = (chunk * 8 + i) / cpg;
+    if (gi != gcur) {
+      atomicAdd(&red[2 * gcur], gs); atomicAdd(&red[2 * gcur + 1], gq);
+      gs = 0.f; gq = 0.f; gcur = gi;
+    }
+    gs += se[i]; gq += qe[i];
+  }
+  atomicAdd(&red[2 * gcur], gs); atomicAdd(&red[2 * gcur + 1], gq);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(int64_t)b * 2 * G + i], (double)red[i]);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const double* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                        const bf16_t* __restrict__ beta, int B, int H, int W, int C, int G,
+                                                        float eps, int silu) {
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)B * H * W * c8;
+  const int cpg = C / G;
+  const double cnt = (double)H * W * cpg;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int chunk = (int)(i % c8);
+    int64_t p = i / c8;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    const int64_t off = (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + chunk * 8;
+    const u32x4 u = *reinterpret_cast<const u32x4*>(x + off);
+    const u32x4 gu = *reinterpret_cast<const u32x4*>(gamma + chunk * 8);
+    const u32x4 bu = *reinterpret_cast<const u32x4*>(beta + chunk * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[2] = {bf16lo(u[j]), bf16hi(u[j])};
+      const float gm[2] = {bf16lo(gu[j]), bf16hi(gu[j])};
+      const float bt[2] = {bf16lo(bu[j]), bf16hi(bu[j])};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int g = (chunk * 8 + 2 * j + e) / cpg;
+        const double sm = stats[((int64_t)b * G + g) * 2], sq = stats[((int64_t)b * G + g) * 2 + 1];
+        const double mean = sm / cnt;
+        const double var = sq / cnt - mean * mean;
+        const float rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+        float t = (v[e] - (float)mean) * rstd * gm[e] + bt[e];
+        if (silu) t = silu_f(t);
+        v[e] = t;
+      }
+      o[j] = pack_bf16x2(v[0], v[1]);
+    }
+    *reinterpret_cast<u32x4*>(y + off) = o;
+  }
+}
+
+// row softmax: p = softmax(scale * s) over `cols`, f32 in -> bf16 out. One workgroup per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int cols,
+                                                            float scale) {
+  __shared__ float red[8];
+  const float* row = s + (int64_t)blockIdx.x * cols;
+  bf16_t* out = p + (int64_t)blockIdx.x * cols;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x * 4; i < cols; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  const float c = scale * 1.4426950408889634f;
+  for (int i = threadIdx.x * 4; i < cols; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += exp2f((v[j] - mx) * c);
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = threadIdx.x * 4; i < cols; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    u32x2 o;
+    o[0] = pack_bf16x2(exp2f((v[0] - mx) * c) * inv, exp2f((v[1] - mx) * c) * inv);
+    o[1] = pack_bf16x2(exp2f((v[2] - mx) * c) * inv, exp2f((v[3] - mx) * c) * inv);
+    *reinterpret_cast<u32x2*>(out + i) = o;
+  }
+}
+
+// out[c][r] = in[r][c] through a 64×64 LDS tile (bf16)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                              int R, int C, int64_t ld_in, int64_t ld_out) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(int64_t)(r0 + r) * ld_in + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && r0 + r < R) out[(int64_t)(c0 + c) * ld_out + r0 + r] = tile[r][c];
+  }
+}
+
+// decoder tail: haloed NHWC f32 [B][H+2][W+2][Cp] -> NCHW f32 [B][C][H][W] and uint8 HWC = round(clamp(x/2+0.5,0,1)*255)
+__global__ void image_out_kernel(const float* __restrict__ x, float* __restrict__ nchw, uint8_t* __restrict__ u8, int B,
+                                 int H, int W, int Cp, int C) {
+  const int64_t n = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    const float* src = x + (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Cp;
+    for (int c = 0; c < C; ++c) {
+      const float v = src[c];
+      if (nchw) nchw[(((int64_t)b * C + c) * H + yy) * W + xx] = v;
+      if (u8) {
+        const float t = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f) * 255.f;
+        u8[i * C + c] = (uint8_t)rintf(t);
+      }
+    }
+  }
+}
+
+// image pre-processing + halo: NCHW f32 [B][C][H][W] -> haloed NHWC bf16 [B][H+2][W+2][Cp] (channels >= C zero)
+__global__ void nchw_to_haloed_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int C, int H, int W,
+                                           int Cp) {
+  const int64_t n = (int64_t)B * H * W * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int c = (int)(p % Cp); p /= Cp;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    const float v = c < C ? x[(((int64_t)b * C + c) * H + yy) * W + xx] : 0.f;
+    y[(((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Cp + c] = f32_to_bf16(v);
+  }
+}
+
+// haloed NHWC bf16 -> NCHW f32 (encoder moments / generic readout)
+__global__ void haloed_nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W,
+                                           int Cp) {
+  const int64_t n = (int64_t)B * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H); p /= H;
+    const int c = (int)(p % C);
+    const int b = (int)(p / C);
+    y[i] = bf16_to_f32(x[(((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Cp + c]);
+  }
+}
+
+// packed latents [B][(H2/2)(W2/2)][4C] bf16 -> haloed NHWC bf16 [B][H2+2][W2+2][Cp], value/scaling + shift (PIPE:1136-1137)
+__global__ void unpack_to_haloed_kernel(const bf16_t* __restrict__ p, bf16_t* __restrict__ y, int B, int C, int H2, int W2,
+                                        int Cp, float inv_scale, float shift) {
+  const int64_t n = (int64_t)B * H2 * W2 * Cp;
+  const int w = W2 / 2, h = H2 / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c = (int)(t % Cp); t /= Cp;
+    const int xx = (int)(t % W2); t /= W2;
+    const int yy = (int)(t % H2);
+    const int b = (int)(t / H2);
+    float v = 0.f;
+    if (c < C) {
+      const int tok = (yy >> 1) * w + (xx >> 1);
+      const int ch = c * 4 + (yy & 1) * 2 + (xx & 1);
+      v = bf16_to_f32(p[((int64_t)b * h * w + tok) * (C * 4) + ch]) * inv_scale + shift;
+    }
+    y[(((int64_t)b * (H2 + 2) + yy + 1) * (W2 + 2) + xx + 1) * Cp + c] = f32_to_bf16(v);
+  }
+}
+
+inline int grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y, int32_t B, int32_t Hs,
+                   int32_t Ws, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t upsample2x,
+                   int32_t out_f32, void* stream) {
+  if (!x || !w || !y || B < 1 || Hs < 1 || Ws < 1 || Cin < 1 || Cout < 1) return RT_E_BADARG;
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && (upsample2x || ksize != 3)))
+    return RT_E_SHAPE;
+  if (Cin % 64 || Cout % 4) return RT_E_SHAPE;
+  if (stride == 2 && (Hs % 2 || Ws % 2)) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(w, 16) || !RT_ALIGNED(y, 16)) return RT_E_ALIGN;
+  ConvArgs a;
+  a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.y = y;
+  a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.stride = stride; a.ups = upsample2x ? 1 : 0;
+  a.Ho = stride == 2 ? Hs / 2 : (upsample2x ? 2 * Hs : Hs);
+  a.Wo = stride == 2 ? Ws / 2 : (upsample2x ? 2 * Ws : Ws);
+  a.out_f32 = out_f32;
+  const int64_t M = (int64_t)B * a.Ho * a.Wo;
+  if (M > 0x7fffffff) return RT_E_SHAPE;
+  const int tiles = (int)((M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nhwc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_nhwc_kernel, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, a);
+  return rt_hip_status();
+}
+
+int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, void* stats_ws, int32_t B,
+                           int32_t H, int32_t W, int32_t C, int32_t G, float eps, int32_t silu, void* stream) {
+  if (!x || !y || !gamma || !beta || !stats_ws || B < 1 || H < 1 || W < 1 || C < 8 || G < 1) return RT_E_BADARG;
+  if (C % 8 || C % G || 256 % (C / 8) || C / 8 > 256) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(y, 16) || !RT_ALIGNED(gamma, 16) || !RT_ALIGNED(beta, 16)) return RT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, (size_t)B * G * 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  const int HW = H * W;
+  const int ppb = 1024;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), (size_t)2 * G * sizeof(float), st,
+                     (const bf16_t*)x, (double*)stats_ws, B, H, W, C, G, ppb);
+  const int64_t total = (int64_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+                     (const double*)stats_ws, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, eps, silu);
+  return rt_hip_status();
+}
+
+int rt_softmax_rows(const float* s, void* p, int32_t rows, int32_t cols, float scale, void* stream) {
+  if (!s || !p || rows < 1 || cols < 4) return RT_E_BADARG;
+  if (cols % 4) return RT_E_SHAPE;
+  if (!RT_ALIGNED(s, 16) || !RT_ALIGNED(p, 8)) return RT_E_ALIGN;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, cols, scale);
+  return rt_hip_status();
+}
+
+int rt_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out, void* stream) {
+  if (!in || !out || R < 1 || C < 1 || ld_in < C || ld_out < R) return RT_E_BADARG;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, (bf16_t*)out, R, C, ld_in, ld_out);
+  return rt_hip_status();
+}
+
+int rt_image_out(const float* x, float* nchw, uint8_t* u8, int32_t B, int32_t H, int32_t W, int32_t Cp, int32_t C,
+                 void* stream) {
+  if (!x || (!nchw && !u8) || B < 1 || H < 1 || W < 1 || C < 1 || Cp < C) return RT_E_BADARG;
+  hipLaunchKernelGGL(image_out_kernel, dim3(grid_for((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, nchw,
+                     u8, B, H, W, Cp, C);
+  return rt_hip_status();
+}
+
+int rt_nchw_to_haloed_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream) {
+  if (!x || !y || B < 1 || C < 1 || H < 1 || W < 1 || Cp < C) return RT_E_BADARG;
+  hipLaunchKernelGGL(nchw_to_haloed_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * Cp, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, (bf16_t*)y, B, C, H, W, Cp);
+  return rt_hip_status();
+}
+
+int rt_haloed_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream) {
+  if (!x || !y || B < 1 || C < 1 || H < 1 || W < 1 || Cp < C) return RT_E_BADARG;
+  hipLaunchKernelGGL(haloed_nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, y, B, C, H, W, Cp);
+  return rt_hip_status();
+}
+
+int rt_unpack_latents_haloed(const void* packed, void* y, int32_t B, int32_t C, int32_t H2, int32_t W2, int32_t Cp,
+                             float inv_scale, float shift, void* stream) {
+  if (!packed || !y || B < 1 || C < 1 || H2 < 2 || W2 < 2 || H2 % 2 || W2 % 2 || Cp < C) return RT_E_BADARG;
+  hipLaunchKernelGGL(unpack_to_haloed_kernel, dim3(grid_for((int64_t)B * H2 * W2 * Cp, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)packed, (bf16_t*)y, B, C, H2, W2, Cp, inv_scale, shift);
+  return rt_hip_status();
+}
+
+}  // extern "C"

@@ -64,13 +64,17 @@ SIGNATURES = {
     "rt_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
     "rt_masked_accumulate": [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp],
 }
-# AutoencoderKL decoder entries (csrc/vae.hip)
-VAE_SIGNATURES = {
-    "rt_groupnorm_silu_nhwc": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
-    "rt_conv2d_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
-    "rt_nhwc_to_nchw_f32": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
-    "rt_attention_vae": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
-}
+# AutoencoderKL entries (csrc/vae.hip)
+SIGNATURES.update({
+    "rt_groupnorm_silu_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "rt_conv2d_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "rt_softmax_rows": [_vp, _vp, _i32, _i32, _f32, _vp],
+    "rt_transpose_bf16": [_vp, _vp, _i32, _i32, _i64, _i64, _vp],
+    "rt_image_out": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "rt_nchw_to_haloed_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "rt_haloed_nhwc_to_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "rt_unpack_latents_haloed": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+})
 
 _lib = None
 
@@ -92,7 +96,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.rt_version.restype = C.c_char_p
     lib.rt_version.argtypes = []
-    for name, argtypes in SIGNATURES.items():  # TODO(vae.hip): merge VAE_SIGNATURES once those kernels land
+    for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_int

@@ -227,8 +227,9 @@ def euler_step_(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> torch.Tensor
 
 
 def cfg_mix(v_uncond: torch.Tensor, v_text: torch.Tensor, s: float) -> torch.Tensor:
-    out = torch.empty_like(v_text)
-    native.check("rt_cfg_mix", native.load().rt_cfg_mix(_dev(v_uncond.contiguous(), "u", BF16), _dev(v_text.contiguous(), "t", BF16), out.data_ptr(), float(s), out.numel(), _stream()))
+    u, t = v_uncond.contiguous(), v_text.contiguous()
+    out = torch.empty_like(t)
+    native.check("rt_cfg_mix", native.load().rt_cfg_mix(_dev(u, "u", BF16), _dev(t, "t", BF16), out.data_ptr(), float(s), out.numel(), _stream()))
     return out
 
 

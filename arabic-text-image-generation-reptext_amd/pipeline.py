@@ -1,0 +1,504 @@
+"""FluxControlNetPipeline (text-to-image with RepText glyph conditions) on the MI355X kernels.
+
+Interface parity target: /root/reference/RepText/pipeline_flux_controlnet.py
+  * constructor components ........................ PIPE:194-226
+  * __call__ keyword names / defaults / returns ... PIPE:751-781, 1132-1148
+  * check_inputs errors ........................... PIPE:485-531
+  * helper statics (ids, pack, unpack) ............ PIPE:533-570
+  * latent / hint preparation ..................... PIPE:573-731
+  * denoising loop semantics (quirks Q1-Q5) ....... PIPE:1016-1130, SURVEY.md §8a
+The control flow is organised as plan -> prepare -> denoise -> decode stages over device-resident state; the
+per-step work is a fixed sequence of HIP launches (mmdit.py) with the regional mask and the sum over text lines fused
+into the ControlNet's zero-linear epilogues.
+"""
+from __future__ import annotations
+
+import contextlib
+import inspect
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .controlnet import FluxControlNetModel, FluxMultiControlNetModel
+from .image_processor import PipelineImageInput, VaeImageProcessor
+from .scheduler import FlowMatchEulerDiscreteScheduler, calculate_shift
+from .transformer import FluxTransformer2DModel
+from .utils import randn_tensor
+from .vae import AutoencoderKL
+
+
+@dataclass
+class FluxPipelineOutput:
+    images: Any
+
+
+def retrieve_latents(encoder_output, generator: Optional[torch.Generator] = None, sample_mode: str = "sample"):
+    """PIPE:91-101."""
+    if hasattr(encoder_output, "latent_dist") and sample_mode == "sample":
+        return encoder_output.latent_dist.sample(generator)
+    if hasattr(encoder_output, "latent_dist") and sample_mode == "argmax":
+        return encoder_output.latent_dist.mode()
+    if hasattr(encoder_output, "latents"):
+        return encoder_output.latents
+    raise AttributeError("Could not access latents of provided encoder_output")
+
+
+def retrieve_timesteps(scheduler, num_inference_steps: Optional[int] = None, device=None, timesteps: Optional[List[int]] = None,
+                       sigmas: Optional[List[float]] = None, **kwargs):
+    """PIPE:104-160: drive ``scheduler.set_timesteps`` with a step count, custom timesteps or custom sigmas."""
+    if timesteps is not None and sigmas is not None:
+        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
+    accepted = set(inspect.signature(scheduler.set_timesteps).parameters.keys())
+    if timesteps is not None:
+        if "timesteps" not in accepted:
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                             f" timestep schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+    elif sigmas is not None:
+        if "sigmas" not in accepted:
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                             f" sigmas schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(sigmas=sigmas, device=device, **kwargs)
+    else:
+        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, len(scheduler.timesteps)
+
+
+class _Progress:
+    def __init__(self, total, disable=False):
+        self.bar = None
+        if not disable:
+            try:
+                from tqdm.auto import tqdm
+
+                self.bar = tqdm(total=total)
+            except Exception:
+                self.bar = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        if self.bar is not None:
+            self.bar.close()
+
+    def update(self, n=1):
+        if self.bar is not None:
+            self.bar.update(n)
+
+
+class FluxControlNetPipeline:
+    model_cpu_offload_seq = "text_encoder->text_encoder_2->transformer->vae"
+    _optional_components: List[str] = []
+    _callback_tensor_inputs = ["latents", "prompt_embeds"]
+
+    def __init__(self, scheduler: FlowMatchEulerDiscreteScheduler, vae: AutoencoderKL, text_encoder, tokenizer, text_encoder_2,
+                 tokenizer_2, transformer: FluxTransformer2DModel,
+                 controlnet: Union[FluxControlNetModel, List[FluxControlNetModel], Tuple[FluxControlNetModel], FluxMultiControlNetModel]):
+        self.vae, self.text_encoder, self.text_encoder_2 = vae, text_encoder, text_encoder_2
+        self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
+        self.transformer, self.scheduler, self.controlnet = transformer, scheduler, controlnet
+        self.vae_scale_factor = 2 ** len(self.vae.config.block_out_channels) if self.vae is not None else 16       # Q9
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self.tokenizer_max_length = self.tokenizer.model_max_length if self.tokenizer is not None else 77
+        self.default_sample_size = 64
+        self._guidance_scale, self._joint_attention_kwargs, self._interrupt, self._num_timesteps = 1.0, None, False, 0
+        self._progress_disabled = False
+
+    # ------------------------------------------------------------------ component plumbing
+    @property
+    def components(self) -> Dict[str, Any]:
+        return dict(scheduler=self.scheduler, vae=self.vae, text_encoder=self.text_encoder, tokenizer=self.tokenizer,
+                    text_encoder_2=self.text_encoder_2, tokenizer_2=self.tokenizer_2, transformer=self.transformer,
+                    controlnet=self.controlnet)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet=None, torch_dtype=None, **kwargs):
+        """Local-directory loader in the diffusers layout (model_index.json + one sub-folder per component; SURVEY.md
+        Appendix B). Text encoders/tokenizers load through `transformers` when their folders exist, else stay None and
+        the caller passes ``prompt_embeds``/``pooled_prompt_embeds``."""
+        root = pretrained_model_name_or_path
+        if not os.path.isdir(root):
+            raise OSError(f"FluxControlNetPipeline.from_pretrained: '{root}' is not a local directory; hub ids such as "
+                          "'black-forest-labs/FLUX.1-dev' need network access. Download the snapshot and pass its path.")
+        dt = torch_dtype or torch.bfloat16
+        sched_cfg = {}
+        sp = os.path.join(root, "scheduler", "scheduler_config.json")
+        if os.path.isfile(sp):
+            with open(sp) as f:
+                sched_cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        known = set(FlowMatchEulerDiscreteScheduler().config.keys())
+        scheduler = FlowMatchEulerDiscreteScheduler(**{k: v for k, v in sched_cfg.items() if k in known})
+        transformer = kwargs.pop("transformer", None) or FluxTransformer2DModel.from_pretrained(root, torch_dtype=dt, subfolder="transformer")
+        vae = kwargs.pop("vae", None) or AutoencoderKL.from_pretrained(root, torch_dtype=dt, subfolder="vae")
+        te = te2 = tok = tok2 = None
+        try:
+            if os.path.isdir(os.path.join(root, "text_encoder")):
+                from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5TokenizerFast
+
+                te = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", torch_dtype=dt)
+                tok = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer")
+                te2 = T5EncoderModel.from_pretrained(root, subfolder="text_encoder_2", torch_dtype=dt)
+                tok2 = T5TokenizerFast.from_pretrained(root, subfolder="tokenizer_2")
+        except Exception as e:  # pragma: no cover - depends on local files
+            raise OSError(f"could not load text encoders from {root}: {e}") from e
+        extra = {k: kwargs[k] for k in ("controlnet_inpaint",) if k in kwargs}
+        return cls(scheduler=scheduler, vae=vae, text_encoder=te, tokenizer=tok, text_encoder_2=te2, tokenizer_2=tok2,
+                   transformer=transformer, controlnet=controlnet, **extra)
+
+    def to(self, device=None, dtype=None):
+        for m in self.components.values():
+            if isinstance(m, torch.nn.Module):
+                m.to(device=device, dtype=dtype) if dtype is not None else m.to(device)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    def maybe_free_model_hooks(self):
+        """Offload hooks belong to accelerate-based CPU offload, which this single-device path does not use (no-op)."""
+
+    def set_progress_bar_config(self, disable: bool = False, **kw):
+        self._progress_disabled = disable
+
+    def progress_bar(self, total=None):
+        return _Progress(total, disable=self._progress_disabled)
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def joint_attention_kwargs(self):
+        return self._joint_attention_kwargs
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    # ------------------------------------------------------------------ prompt encoding (PIPE:232-456)
+    def _require_text_stack(self):
+        if self.text_encoder is None or self.text_encoder_2 is None or self.tokenizer is None or self.tokenizer_2 is None:
+            raise ValueError("this pipeline was built without text encoders/tokenizers: pass `prompt_embeds` and "
+                             "`pooled_prompt_embeds` instead of `prompt`")
+
+    def _get_t5_prompt_embeds(self, prompt, num_images_per_prompt=1, max_sequence_length=512, device=None, dtype=None):
+        self._require_text_stack()
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        tok = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                               return_length=False, return_overflowing_tokens=False, return_tensors="pt")
+        emb = self.text_encoder_2(tok.input_ids.to(device), output_hidden_states=False)[0]
+        emb = emb.to(dtype=self.text_encoder_2.dtype, device=device)
+        b, seq, _ = emb.shape
+        return emb.repeat(1, num_images_per_prompt, 1).view(b * num_images_per_prompt, seq, -1)
+
+    def _get_clip_prompt_embeds(self, prompt, num_images_per_prompt=1, device=None):
+        self._require_text_stack()
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        tok = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer_max_length, truncation=True,
+                             return_overflowing_tokens=False, return_length=False, return_tensors="pt")
+        pooled = self.text_encoder(tok.input_ids.to(device), output_hidden_states=False).pooler_output
+        pooled = pooled.to(dtype=self.text_encoder.dtype, device=device)
+        return pooled.repeat(1, num_images_per_prompt).view(len(prompt) * num_images_per_prompt, -1)
+
+    def encode_prompt(self, prompt, prompt_2, device=None, num_images_per_prompt: int = 1, prompt_embeds=None,
+                      pooled_prompt_embeds=None, max_sequence_length: int = 512, lora_scale=None):
+        """Returns (prompt_embeds [B,L,4096], pooled [B,768], text_ids zeros[L,3]) — PIPE:349-456 (LoRA scaling is inert:
+        no PEFT on this path)."""
+        device = device or self._execution_device
+        if prompt_embeds is None:
+            prompt = [prompt] if isinstance(prompt, str) else prompt
+            prompt_2 = prompt_2 or prompt
+            prompt_2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(prompt, num_images_per_prompt, device)
+            prompt_embeds = self._get_t5_prompt_embeds(prompt_2, num_images_per_prompt, max_sequence_length, device)
+        ids_dtype = self.text_encoder.dtype if self.text_encoder is not None else prompt_embeds.dtype
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device, dtype=ids_dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
+
+    def _encode_vae_image(self, image: torch.Tensor, generator):
+        """PIPE:459-471: sample the posterior (per-sample generators allowed) and apply (z - shift) * scaling."""
+        if isinstance(generator, list):
+            lat = torch.cat([retrieve_latents(self.vae.encode(image[i : i + 1]), generator=generator[i]) for i in range(image.shape[0])], dim=0)
+        else:
+            lat = retrieve_latents(self.vae.encode(image), generator=generator)
+        return (lat - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+
+    # ------------------------------------------------------------------ validation (PIPE:485-531)
+    def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
+                     callback_on_step_end_tensor_inputs=None, max_sequence_length=None):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None:
+            bad = [k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]
+            if bad:
+                raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found {bad}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        if prompt_2 is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt_2`: {prompt_2} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if prompt_2 is not None and not isinstance(prompt_2, (str, list)):
+            raise ValueError(f"`prompt_2` has to be of type `str` or `list` but is {type(prompt_2)}")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make sure to generate "
+                             "`pooled_prompt_embeds` from the same text encoder that was used to generate `prompt_embeds`.")
+        if max_sequence_length is not None and max_sequence_length > 512:
+            raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+
+    # ------------------------------------------------------------------ latent helpers (PIPE:533-570)
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        """(0,row,col) per token of the (height/2)x(width/2) grid, row-major (height/width are LATENT sizes)."""
+        rows = torch.arange(height // 2, dtype=torch.float32)
+        cols = torch.arange(width // 2, dtype=torch.float32)
+        ids = torch.stack([torch.zeros(height // 2, width // 2), rows[:, None].expand(-1, width // 2),
+                           cols[None, :].expand(height // 2, -1)], dim=-1)
+        return ids.reshape(-1, 3).to(device=device, dtype=dtype)
+
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        """[B,C,H,W] -> [B,(H/2)(W/2),4C] with channel order (c,dy,dx). GPU bf16 tensors use the HIP kernel."""
+        if latents.is_cuda and latents.dtype == torch.bfloat16:
+            return ops.pack_latents(latents.reshape(batch_size, num_channels_latents, height, width))
+        x = latents.reshape(batch_size, num_channels_latents, height // 2, 2, width // 2, 2)
+        return x.permute(0, 2, 4, 1, 3, 5).reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        b, _, ch = latents.shape
+        h, w = height // vae_scale_factor, width // vae_scale_factor
+        x = latents.reshape(b, h, w, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+        return x.reshape(b, ch // 4, h * 2, w * 2)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        h2 = 2 * (int(height) // self.vae_scale_factor)
+        w2 = 2 * (int(width) // self.vae_scale_factor)
+        ids = self._prepare_latent_image_ids(batch_size, h2, w2, device, dtype)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), ids
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        noise = randn_tensor((batch_size, num_channels_latents, h2, w2), generator=generator, device=device, dtype=dtype)
+        return self._pack_latents(noise, batch_size, num_channels_latents, h2, w2), ids
+
+    def _glyph_blend(self, image, image_latents, noise):
+        """0.10·glyph latent + noise where the bilinearly down-sampled glyph mask is > 0 (PIPE:645-654)."""
+        m = (image > 0).any(dim=1, keepdim=True).float()
+        m = F.interpolate(m, size=noise.shape[-2:], mode="bilinear", align_corners=False) > 0
+        return torch.where(m, 0.10 * image_latents + noise, noise)
+
+    def prepare_latents_reptext(self, image, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """PIPE:608-660 including quirk Q1: the glyph image IS VAE-encoded with `generator` (advancing its stream by one
+        [B,16,h,w] normal draw) and the blended result is computed, but the returned latents are the plain noise."""
+        h2 = 2 * (int(height) // self.vae_scale_factor)
+        w2 = 2 * (int(width) // self.vae_scale_factor)
+        image = image.to(device=device, dtype=dtype)
+        image_latents = self._encode_vae_image(image=image, generator=generator)
+        n_img = image_latents.shape[0]
+        if batch_size > n_img and batch_size % n_img == 0:
+            image_latents = torch.cat([image_latents] * (batch_size // n_img), dim=0)
+        elif batch_size > n_img:
+            raise ValueError(f"Cannot duplicate `image` of batch size {n_img} to {batch_size} text prompts.")
+        ids = self._prepare_latent_image_ids(batch_size, h2, w2, device, dtype)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), ids
+        noise = randn_tensor((batch_size, num_channels_latents, h2, w2), generator=generator, device=device, dtype=dtype)
+        _unused_blend = self._glyph_blend(image, image_latents, noise)   # computed and dropped, as in the reference (Q1)
+        return self._pack_latents(noise, batch_size, num_channels_latents, h2, w2), ids
+
+    def _prep_pixels(self, image, width, height, batch_size, num_images_per_prompt, device, dtype):
+        if not isinstance(image, torch.Tensor):
+            image = self.image_processor.preprocess(image, height=height, width=width)
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        return image.repeat_interleave(repeat_by, dim=0).to(device=device, dtype=dtype)
+
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, image_position=None,
+                      do_classifier_free_guidance=False, guess_mode=False):
+        """PIPE:663-731: VAE-encode the canny hint and the (3-channel repeated) position hint, concatenate on channels,
+        pack -> [B, N, 128]. Both posteriors are sampled from the GLOBAL torch RNG (no generator; quirk Q2)."""
+        image = self._prep_pixels(image, width, height, batch_size, num_images_per_prompt, device, dtype)
+        pos = self._prep_pixels(image_position, width, height, batch_size, num_images_per_prompt, device, dtype).repeat(1, 3, 1, 1)
+        sf, sc = self.vae.config.shift_factor, self.vae.config.scaling_factor
+        lat = ((self.vae.encode(image.to(self.vae.dtype)).latent_dist.sample() - sf) * sc).to(dtype)
+        plat = ((self.vae.encode(pos.to(self.vae.dtype)).latent_dist.sample() - sf) * sc).to(dtype)
+        both = torch.cat([lat, plat], dim=1)
+        packed = self._pack_latents(both, batch_size * num_images_per_prompt, both.shape[1], both.shape[2], both.shape[3])
+        if do_classifier_free_guidance:
+            packed = torch.cat([packed] * 2)
+        return packed, height, width
+
+    def _region_masks(self, control_mask, device, dtype) -> List[torch.Tensor]:
+        """PIPE:1007-1013: mask/255 -> bilinear x1/16 -> [1, N, 1]."""
+        out = []
+        if control_mask is not None:
+            for m in control_mask:
+                rm = torch.from_numpy(np.array(m)) / 255.0
+                t = F.interpolate(rm[None, None].float(), scale_factor=1 / 16, mode="bilinear").reshape([1, -1, 1])
+                out.append(t.to(device=device, dtype=dtype))
+        return out
+
+    def _is_packed_hint(self, t) -> bool:
+        cn = self.controlnet
+        return isinstance(t, torch.Tensor) and t.dim() == 3 and isinstance(cn, FluxControlNetModel) and \
+            t.shape[-1] == cn.controlnet_x_embedder.weight.shape[1]
+
+    # ------------------------------------------------------------------ the call
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]] = None, prompt_2: Optional[Union[str, List[str]]] = None,
+                 height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 28,
+                 timesteps: List[int] = None, guidance_scale: float = 7.0,
+                 control_guidance_start: Union[float, List[float]] = 0.0, control_guidance_end: Union[float, List[float]] = 1.0,
+                 control_image: PipelineImageInput = None, control_mode: Optional[Union[int, List[int]]] = None,
+                 controlnet_conditioning_scale: Union[float, List[float]] = 1.0, controlnet_conditioning_step: int = 30,
+                 num_images_per_prompt: Optional[int] = 1,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 latents: Optional[torch.FloatTensor] = None, prompt_embeds: Optional[torch.FloatTensor] = None,
+                 pooled_prompt_embeds: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pil",
+                 return_dict: bool = True, joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+                 callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 512,
+                 control_mask: Optional[torch.FloatTensor] = None, control_position: Optional[torch.FloatTensor] = None,
+                 control_glyph: Optional[torch.FloatTensor] = None):
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        # control_guidance_start/end are normalised like the reference but have no effect on the result (inert: Q3)
+        self.check_inputs(prompt, prompt_2, height, width, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+                          callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs, max_sequence_length=max_sequence_length)
+        self._guidance_scale, self._joint_attention_kwargs, self._interrupt = guidance_scale, joint_attention_kwargs, False
+
+        if isinstance(prompt, str):
+            batch_size = 1
+        elif isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        device, dtype = self._execution_device, self.transformer.dtype
+        total = batch_size * num_images_per_prompt
+
+        prompt_embeds, pooled_prompt_embeds, text_ids = self.encode_prompt(
+            prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds, device=device,
+            num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length)
+        prompt_embeds = prompt_embeds.to(device=device)
+        pooled_prompt_embeds = pooled_prompt_embeds.to(device=device)
+
+        # hints: one packed [B,N,128] tensor per text line (PIPE:928-942). Tensors that are already packed hint latents
+        # ([B,N,in+extra]) are taken as they are — an extension used by the benchmarks and the multi-GPU broadcast.
+        hints: List[torch.Tensor] = []
+        if isinstance(self.controlnet, FluxControlNetModel) and control_image is not None:
+            positions = control_position if control_position is not None else [None] * len(control_image)
+            for img, pos in zip(control_image, positions):
+                if self._is_packed_hint(img):
+                    hints.append(img.to(device=device, dtype=dtype))
+                else:
+                    h, height, width = self.prepare_image(image=img, image_position=pos, width=width, height=height, batch_size=total,
+                                                          num_images_per_prompt=num_images_per_prompt, device=device, dtype=dtype)
+                    hints.append(h)
+
+        num_channels_latents = self.transformer.config.in_channels // 4
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        image_seq_len = (int(height) // self.vae_scale_factor) * (int(width) // self.vae_scale_factor)
+        sc = self.scheduler.config
+        mu = calculate_shift(image_seq_len, sc.base_image_seq_len, sc.max_image_seq_len, sc.base_shift, sc.max_shift)
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, sigmas, mu=mu)
+
+        if control_glyph is not None:
+            init_image = self.image_processor.preprocess(control_glyph, height=height, width=width).to(dtype=torch.float32)
+            latents, latent_image_ids = self.prepare_latents_reptext(init_image, total, num_channels_latents, height, width,
+                                                                     prompt_embeds.dtype, device, generator, None)
+        else:
+            latents, latent_image_ids = self.prepare_latents(total, num_channels_latents, height, width, prompt_embeds.dtype, device,
+                                                             generator, latents)
+        self._num_timesteps = len(timesteps)
+        masks = self._region_masks(control_mask, latents.device, latents.dtype)
+
+        latents = self._denoise(latents, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, timesteps, hints, masks,
+                                guidance_scale, controlnet_conditioning_scale, controlnet_conditioning_step, control_mode,
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, num_inference_steps)
+
+        if output_type == "latent":
+            image = latents
+        else:
+            h2 = 2 * (int(height) // self.vae_scale_factor)
+            w2 = 2 * (int(width) // self.vae_scale_factor)
+            if output_type in ("pil", "np"):
+                u8 = self.vae.decode_packed(latents, h2, w2, output_u8=True)
+                image = self.image_processor.postprocess_u8(u8, output_type)
+            elif output_type == "pt":
+                image = (self.vae.decode_packed(latents, h2, w2) / 2 + 0.5).clamp(0, 1)
+            else:
+                raise ValueError(f"unsupported output_type {output_type}")
+        self.maybe_free_model_hooks()
+        if not return_dict:
+            return (image,)
+        return FluxPipelineOutput(images=image)
+
+    # ------------------------------------------------------------------ hot loop (PIPE:1016-1130)
+    def _denoise(self, latents, prompt_embeds, pooled, text_ids, image_ids, timesteps, hints, masks, guidance_scale,
+                 cn_scale, cn_steps, control_mode, callback, callback_inputs, num_inference_steps):
+        device = latents.device
+        B = latents.shape[0]
+        tvals = timesteps.to(torch.float32).cpu().tolist()                 # host copies: no per-step device sync
+        guidance = torch.full((B,), float(guidance_scale), device=device, dtype=torch.float32) if self.transformer.config.guidance_embeds else None
+        rowscales = [m.reshape(-1).to(torch.float32).contiguous() for m in masks]
+        num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i, t in enumerate(tvals):
+                if self.interrupt:
+                    continue
+                timestep = torch.full((B,), t / 1000.0, device=device, dtype=torch.float32)      # PIPE:1025,1048 (Q4)
+                merged = merged_single = None
+                for line, hint in enumerate(hints):
+                    if i >= cn_steps:                                                             # Q3
+                        samples = single_samples = None
+                    else:
+                        rs = rowscales[line] if rowscales else None
+                        samples, single_samples = self.controlnet(
+                            hidden_states=latents, controlnet_cond=hint, controlnet_mode=control_mode, conditioning_scale=cn_scale,
+                            timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=prompt_embeds,
+                            txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs,
+                            return_dict=False, _rowscale=rs, _accumulate_into=merged if line > 0 else None,
+                            _accumulate_single_into=merged_single if line > 0 else None)
+                    if line == 0:
+                        merged, merged_single = samples, single_samples
+                    # line > 0: the zero-linear epilogues already summed into `merged` (PIPE:1076-1087)
+                noise_pred = self.transformer(
+                    hidden_states=latents, timestep=timestep, guidance=guidance, pooled_projections=pooled,
+                    encoder_hidden_states=prompt_embeds, controlnet_block_samples=merged, controlnet_single_block_samples=merged_single,
+                    txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False)[0]
+                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+                if callback is not None:
+                    env = {"latents": latents, "prompt_embeds": prompt_embeds}
+                    out = callback(self, i, timesteps[i], {k: env[k] for k in callback_inputs})
+                    latents = out.pop("latents", latents)
+                    prompt_embeds = out.pop("prompt_embeds", prompt_embeds)
+                if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
+                    bar.update()
+        return latents

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FLUX.1-dev + RepText ControlNet, 1024x1024, 28 steps, bf16, synthetic Arabic-glyph hints.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one batch: 28 denoising steps (ControlNet tower + transformer + Euler
+step each) followed by the VAE decode to uint8, for `--batch-per-gpu` images on every rank (BASELINE.json configs[1];
+SURVEY.md §8d timed region). Inputs (prompt embeddings, packed hint latents, regional mask, initial noise) are resident
+in HBM before the timed region. Weights are random-init FLUX.1-dev / RepText shapes (no checkpoints offline).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed passes (images per GPU x batch)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--inference-steps", type=int, default=28)
+    ap.add_argument("--text-lines", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--depth-scale", type=float, default=1.0, help="DEBUG ONLY: scale layer counts (result flagged invalid)")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------- work model
+def flops_per_image(H, W, steps, lines, cfg_t, cfg_c):
+    d = cfg_t["num_attention_heads"] * cfg_t["attention_head_dim"]
+    T, N = 512, (H // 16) * (W // 16)
+    S = T + N
+    block = 24 * S * d * d + 4 * S * S * d
+    tr = (cfg_t["num_layers"] + cfg_t["num_single_layers"]) * block + 2 * N * 64 * d + 2 * T * 4096 * d + 2 * N * d * 64
+    L = cfg_c["num_layers"] + cfg_c["num_single_layers"]
+    cn = L * block + L * 2 * N * d * d + 2 * N * 64 * d + 2 * N * (64 + cfg_c["extra_condition_channels"]) * d + 2 * T * 4096 * d
+    return steps * (tr + lines * cn)
+
+
+def synthetic_glyph_hint(height, width, text="مرحبا"):
+    """PIL-rendered Arabic glyph on black + bbox position/region masks (host, once). Falls back to a plain box when no
+    font with Arabic coverage is installed (the hint only sets mask geometry for the benchmark)."""
+    import numpy as np
+    from PIL import Image, ImageDraw, ImageFont
+
+    img = Image.new("RGB", (width, height), (0, 0, 0))
+    draw = ImageDraw.Draw(img)
+    pos = (int(width * 0.36), int(height * 0.2))
+    try:
+        font = ImageFont.truetype("DejaVuSans.ttf", max(height // 13, 12))
+        draw.text(pos, text, font=font, fill=(255, 255, 255))
+        bbox = draw.textbbox(pos, text, font=font)
+    except Exception:
+        bbox = (pos[0], pos[1], pos[0] + width // 4, pos[1] + height // 10)
+        draw.rectangle(bbox, fill=(255, 255, 255))
+    mask = np.zeros([height, width], dtype=np.uint8)
+    mask[max(bbox[1] - 5, 0) : bbox[3] + 5, max(bbox[0] - 5, 0) : bbox[2] + 5] = 255
+    return img, bbox, Image.fromarray(mask)
+
+
+class GemmTimer:
+    """HIP-event timing of every rt_gemm_bf16 launch on the stream it is enqueued on (roofline pass only)."""
+
+    def __init__(self, ops_mod):
+        self.ops = ops_mod
+        self.events, self.flops = [], []
+        self._orig = None
+
+    def __enter__(self):
+        ops = self.ops
+        self._orig = ops.linear_grouped
+
+        def timed(problems):
+            fl = 0
+            for p in problems:
+                a, w = p.a, p.w
+                rows = a.shape[0] * a.shape[1] if a.dim() == 3 else a.shape[0]
+                fl += 2 * rows * w.shape[0] * w.shape[1]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()          # records on torch's current stream == the stream ops.py launches on
+            self._orig(problems)
+            e1.record()
+            self.events.append((e0, e1))
+            self.flops.append(fl)
+
+        ops.linear_grouped = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.linear_grouped = self._orig
+
+    def result(self):
+        torch.cuda.synchronize()
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        return len(self.events), sum(self.flops), tot_ms * 1e-3
+
+
+def cpu_baseline(cfg_t, H, W, steps, lines, cfg_c, budget_s=12.0):
+    """Oracle (fp32 torch CPU ops) on a bounded sample: whole MMDiT blocks at the C2 sequence length, extrapolated by
+    block count to one image. Returns the cpu_baseline JSON object."""
+    from oracle import flux_oracle as orc
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    d = cfg_t["num_attention_heads"] * cfg_t["attention_head_dim"]
+    T, N = 512, (H // 16) * (W // 16)
+    small = dict(cfg_t, num_layers=1, num_single_layers=1)
+    p = orc.init_mmdit_params(small, seed=0, round_bf16=False)
+    g = torch.Generator().manual_seed(0)
+    h, e = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g)
+    temb = torch.randn(1, d, generator=g)
+    rope = orc.rope_table(torch.cat([torch.zeros(T, 3), orc.latent_image_ids(2 * (H // 16), 2 * (W // 16))]))
+    x = torch.cat([e, h], dim=1)
+    H_, Dh = cfg_t["num_attention_heads"], cfg_t["attention_head_dim"]
+    td, ts, nd, ns = 0.0, 0.0, 0, 0
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t_start < budget_s or nd == 0:
+            t0 = time.perf_counter(); orc.double_block(p, "transformer_blocks.0", h, e, temb, rope, H_, Dh); td += time.perf_counter() - t0; nd += 1
+            t0 = time.perf_counter(); orc.single_block(p, "single_transformer_blocks.0", x, temb, rope, H_, Dh); ts += time.perf_counter() - t0; ns += 1
+    td, ts = td / nd, ts / ns
+    n_double = cfg_t["num_layers"] + lines * cfg_c["num_layers"]
+    n_single = cfg_t["num_single_layers"] + lines * cfg_c["num_single_layers"]
+    sec_per_image = steps * (n_double * td + n_single * ts)
+    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 torch-CPU: {nd} double + {ns} single MMDiT blocks at S={T+N}, d={d} "
+                      f"({td:.2f}s / {ts:.2f}s each), extrapolated to {steps} steps x ({n_double} double + {n_single} single) blocks; "
+                      "embedders, zero-linears and VAE decode not included"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import reptext_amd.ops as ops
+    from reptext_amd import dist as rdist
+    from reptext_amd.config import flux_dev_transformer_config, flux_vae_config, reptext_controlnet_config
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+    from reptext_amd.vae import AutoencoderKL
+
+    cfg_t, cfg_c = flux_dev_transformer_config(), reptext_controlnet_config()
+    if args.depth_scale != 1.0:
+        cfg_t["num_layers"] = max(1, int(cfg_t["num_layers"] * args.depth_scale))
+        cfg_t["num_single_layers"] = max(1, int(cfg_t["num_single_layers"] * args.depth_scale))
+        cfg_c["num_layers"] = max(1, int(cfg_c["num_layers"] * args.depth_scale))
+    bf16 = torch.bfloat16
+    tkw = {k: v for k, v in cfg_t.items()}
+    transformer = FluxTransformer2DModel(**tkw, device=dev, dtype=bf16).random_init_(seed=0)
+    controlnet = FluxControlNetModel(**cfg_c, device=dev, dtype=bf16).random_init_(seed=1)   # zero-linears random too
+    vae = AutoencoderKL(**flux_vae_config(), device=dev, dtype=bf16).random_init_(seed=2)
+    pipe = FluxControlNetPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=None, tokenizer=None,
+                                  text_encoder_2=None, tokenizer_2=None, transformer=transformer, controlnet=controlnet)
+    pipe.set_progress_bar_config(disable=True)
+
+    H, W, Bl = args.height, args.width, args.batch_per_gpu
+    N = (H // 16) * (W // 16)
+    # ---- conditioning: rank 0 builds it, ONE broadcast; text encoders are outside the timed region
+    spec = [("prompt_embeds", (1, 512, 4096)), ("pooled", (1, 768))] + [(f"hint{i}", (1, N, 128)) for i in range(args.text_lines)] + \
+           [(f"mask{i}", (N,)) for i in range(args.text_lines)]
+    cond = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(1)
+        pe = torch.randn(1, 512, 4096, generator=g)
+        pooled = torch.randn(1, 768, generator=g)
+        g2 = torch.Generator().manual_seed(2)
+        hints = [torch.randn(1, N, 128, generator=g2) for _ in range(args.text_lines)]
+        _, _, mask_img = synthetic_glyph_hint(H, W)
+        m = pipe._region_masks([mask_img] * args.text_lines, "cpu", torch.float32)
+        cond = rdist.Conditioning(pe, pooled, hints, [t.reshape(-1) for t in m])
+    if world > 1:
+        cond = rdist.broadcast_conditioning(cond, spec, dev)
+    else:
+        cond = rdist.Conditioning(cond.prompt_embeds.to(dev, bf16), cond.pooled.to(dev, bf16), [h.to(dev, bf16) for h in cond.hints],
+                                  [m.to(dev) for m in cond.masks])
+    pe = cond.prompt_embeds.expand(Bl, -1, -1).contiguous()
+    pooled = cond.pooled.expand(Bl, -1).contiguous()
+    hints = [h.expand(Bl, -1, -1).contiguous() for h in cond.hints]
+
+    lo, hi = rdist.shard_range(world * Bl, rank, world)
+
+    def one_pass(pass_idx):
+        ids = [pass_idx * world * Bl + s for s in range(lo, hi)]
+        noise = rdist.sample_noise(ids, (16, 2 * (H // 16), 2 * (W // 16)), 42, bf16, dev)
+        lat = pipe._pack_latents(noise, Bl, 16, 2 * (H // 16), 2 * (W // 16))
+        return run_image(pipe, lat, pe, pooled, hints, cond.masks, H, W, args.inference_steps)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        one_pass(-1 - w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = one_pass(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    images = world * Bl * args.steps
+    value = images / elapsed
+    fl_img = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline_pass:
+        with GemmTimer(ops) as gt:
+            one_pass(10 ** 6)
+        n_launch, fl, sec = gt.result()
+        ach = fl / sec / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                    "traffic": None, "kernel": "gemm_bf16_kernel", "launches": n_launch,
+                    "avg_launch_us": round(sec / n_launch * 1e6, 2), "avg_gflop_per_launch": round(fl / n_launch / 1e9, 2),
+                    "e2e_tflops_per_gpu": round(fl_img * Bl * args.steps / elapsed / 1e12, 1),
+                    "e2e_frac": round(fl_img * Bl * args.steps / elapsed / 2.5e15, 4)}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg_t, H, W, args.inference_steps, args.text_lines, cfg_c)
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec (whole node), FLUX.1-dev+RepText CN, 1024^2, 28 steps",
+            "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "sec_per_image": round(elapsed / (args.steps * Bl), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
+                                   f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
+                       "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if args.depth_scale != 1.0:
+            line["INVALID_debug_depth_scale"] = args.depth_scale
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_image(pipe, latents, pe, pooled, hints, rowscales, H, W, steps):
+    """The timed region: set up the schedule (host scalars), run the loop, decode to uint8."""
+    import numpy as np
+    from reptext_amd.pipeline import retrieve_timesteps
+    from reptext_amd.scheduler import calculate_shift
+
+    dev = latents.device
+    sc = pipe.scheduler.config
+    mu = calculate_shift((H // 16) * (W // 16), sc.base_image_seq_len, sc.max_image_seq_len, sc.base_shift, sc.max_shift)
+    timesteps, n = retrieve_timesteps(pipe.scheduler, steps, dev, None, np.linspace(1.0, 1 / steps, steps), mu=mu)
+    h2, w2 = 2 * (H // 16), 2 * (W // 16)
+    B = latents.shape[0]
+    text_ids = torch.zeros(pe.shape[1], 3, device=dev, dtype=latents.dtype)
+    image_ids = pipe._prepare_latent_image_ids(B, h2, w2, dev, latents.dtype)
+    pipe._guidance_scale, pipe._joint_attention_kwargs, pipe._interrupt = 3.5, None, False
+    masks = [m.reshape(1, -1, 1) for m in rowscales]
+    lat = pipe._denoise(latents, pe, pooled, text_ids, image_ids, timesteps, hints, masks, 3.5, 1.0, steps, None, None, [], n)
+    return pipe.vae.decode_packed(lat, h2, w2, output_u8=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -125,9 +125,9 @@ int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream)
 int rt_cfg_mix(const void* v_uncond, const void* v_text, void* out, float s, int64_t n, void* stream);
 
 /* _pack_latents / _unpack_latents (PIPE:550-570): [B][C][2h][2w] <-> [B][h*w][4C], channel order (c,dy,dx).
- * unpack also applies z/scaling + shift (PIPE:1137) and converts to NHWC bf16 for the decoder. */
+ * unpack also applies z/scaling + shift (PIPE:1137) and writes NHWC bf16 [B][H2][W2][C]. */
 int rt_pack_latents(const void* nchw, void* packed, int32_t B, int32_t C, int32_t H2, int32_t W2, void* stream);
-int rt_unpack_latents(const void* packed, void* nchw, int32_t B, int32_t C, int32_t H2, int32_t W2,
+int rt_unpack_latents(const void* packed, void* nhwc, int32_t B, int32_t C, int32_t H2, int32_t W2,
                       float inv_scale, float shift, void* stream);
 
 /* Elementwise helpers on the path. */
@@ -138,22 +138,36 @@ int rt_masked_accumulate(const void* x, void* y, const float* rowscale, float al
                          int32_t batch, int32_t rows, int32_t D, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * AutoencoderKL decoder (PIPE:1139; Appendix A.7). Activations are NHWC bf16.
+ * AutoencoderKL (PIPE:467,705,711 encode; PIPE:1139 decode; Appendix A.7).
+ * Activations are zero-haloed NHWC bf16: [B][H+2][W+2][C]; the halo is allocated zeroed by the caller and never
+ * written by these kernels, so 3x3 gathers need no bounds checks.
  * ---------------------------------------------------------------------------------------- */
-/* GroupNorm(G groups, eps, affine) + optional SiLU over NHWC; x may be upsampled 2x nearest on the fly
- * by the consumer, not here. */
-int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta,
-                           int32_t B, int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, void* stream);
-/* 3x3 (or 1x1) convolution, stride 1, zero pad, as implicit GEMM on MFMA; optional nearest-2x upsample of the
- * input fused into the gather; optional residual add. w is bf16 [Cout][ky][kx][Cin] (repacked from OIHW). */
+/* GroupNorm(G groups, eps, affine gamma/beta bf16 [C]) + optional SiLU over the interior of x -> interior of y.
+ * stats_ws: device scratch of B*G*2 doubles (zeroed inside). C % 8 == 0, C % G == 0, 256 % (C/8) == 0. */
+int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, void* stats_ws,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t G, float eps, int32_t silu, void* stream);
+/* 3x3 / 1x1 convolution as implicit GEMM on MFMA. x haloed [B][Hs+2][Ws+2][Cin], w bf16 [Cout][k][k][Cin] (repacked
+ * from OIHW), y haloed [B][Ho+2][Wo+2][Cout] bf16|f32, res (optional) like y in bf16.
+ *   stride 1: pad k/2; upsample2x fuses a nearest-2x Upsample2D in front (Ho = 2Hs)
+ *   stride 2: k = 3, pad (0,1,0,1) = diffusers Downsample2D (Ho = Hs/2)
+ * Cin % 64 == 0 (callers zero-pad channels), Cout % 4 == 0. */
 int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y,
-                   int32_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t ksize,
+                   int32_t B, int32_t Hs, int32_t Ws, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
                    int32_t upsample2x, int32_t out_f32, void* stream);
-/* Final image write: NHWC bf16/f32 [B][H][W][C<=4 padded] -> NCHW f32 [B][3][H][W]. */
-int rt_nhwc_to_nchw_f32(const void* x, int32_t x_f32, float* y, int32_t B, int32_t HW, int32_t Cpad, int32_t C, void* stream);
-/* Single-head attention for the VAE mid block (A.7): head dim Dh in {512}. q,k,v,o bf16 [B][S][Dh]. */
-int rt_attention_vae(const void* q, const void* k, const void* v, void* o,
-                     int64_t ld, int64_t ldo, int32_t B, int32_t S, int32_t Dh, float scale, void* stream);
+/* Row softmax for the VAE mid-block attention (1 head, Dh = 512, computed as GEMM -> softmax -> GEMM):
+ * p[r][:] = softmax(scale * s[r][:]), f32 in, bf16 out. cols % 4 == 0. */
+int rt_softmax_rows(const float* s, void* p, int32_t rows, int32_t cols, float scale, void* stream);
+/* out[c][r] = in[r][c], bf16 (V^T for the P·V GEMM). */
+int rt_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out, void* stream);
+/* Decoder tail: haloed NHWC f32 [B][H+2][W+2][Cp] -> NCHW f32 [B][C][H][W] (nchw, optional) and/or uint8 HWC
+ * round(clamp(x/2+0.5,0,1)*255) (u8, optional) = VaeImageProcessor.postprocess (PIPE:1140). */
+int rt_image_out(const float* x, float* nchw, uint8_t* u8, int32_t B, int32_t H, int32_t W, int32_t Cp, int32_t C, void* stream);
+/* Encoder head / readout: NCHW f32 <-> haloed NHWC bf16 with channel padding to Cp. */
+int rt_nchw_to_haloed_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream);
+int rt_haloed_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream);
+/* _unpack_latents + z/scaling + shift (PIPE:1136-1137) straight into the decoder's haloed NHWC input. */
+int rt_unpack_latents_haloed(const void* packed, void* y, int32_t B, int32_t C, int32_t H2, int32_t W2, int32_t Cp,
+                             float inv_scale, float shift, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""GPU parity of the AutoencoderKL kernels and of the end-to-end pipeline (BASELINE config C1 shape: 256x256, 2 steps)
+against the fp32 CPU oracle. Reduced-depth / reduced-width random weights, bf16-rounded on both sides."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_oracle as orc  # noqa: E402
+from oracle import vae_oracle as vorc  # noqa: E402
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+VAE_SMALL = dict(vorc.FLUX_VAE_CFG, block_out_channels=(64, 128, 256, 256))   # same topology, 1/2 width: oracle in seconds
+SMALL_T = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=3, attention_head_dim=128, num_attention_heads=4,
+               joint_attention_dim=256, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+SMALL_CN = dict(SMALL_T, num_layers=2, num_single_layers=0, extra_condition_channels=64)
+
+
+@pytest.fixture(scope="module")
+def vae_pair(gpu):
+    from reptext_amd.vae import AutoencoderKL
+
+    p = vorc.init_vae_params(VAE_SMALL, seed=3)
+    vae = AutoencoderKL(**VAE_SMALL, device=gpu, dtype=torch.bfloat16)
+    vae.load_state_dict(p, strict=True)
+    return p, vae
+
+
+def test_conv_kernel_modes(gpu):
+    """conv3x3 / 1x1 / fused nearest-2x / stride-2 pad(0,1,0,1) against torch conv2d."""
+    import torch.nn.functional as F
+
+    from reptext_amd import native
+
+    lib = native.load()
+    g = torch.Generator().manual_seed(0)
+    B, H, W, Cin, Cout = 2, 12, 20, 64, 136
+    x = torch.randn(B, Cin, H, W, generator=g).to(torch.bfloat16).float()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def haloed(t):
+        out = torch.zeros(t.shape[0], t.shape[2] + 2, t.shape[3] + 2, t.shape[1], device=gpu, dtype=torch.bfloat16)
+        out[:, 1:-1, 1:-1, :] = t.permute(0, 2, 3, 1).to(gpu, torch.bfloat16)
+        return out
+
+    xh = haloed(x)
+    for ks, stride, up in [(3, 1, 0), (1, 1, 0), (3, 1, 1), (3, 2, 0)]:
+        w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).to(torch.bfloat16).float()
+        b = torch.randn(Cout, generator=g).to(torch.bfloat16).float()
+        if stride == 2:
+            ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+        elif up:
+            ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+        else:
+            ref = F.conv2d(x, w, b, padding=ks // 2)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        res = torch.randn(B, Cout, Ho, Wo, generator=g).to(torch.bfloat16).float()
+        y = torch.zeros(B, Ho + 2, Wo + 2, Cout, device=gpu, dtype=torch.bfloat16)
+        wp = w.permute(0, 2, 3, 1).contiguous().to(gpu, torch.bfloat16)
+        bd, rh = b.to(gpu, torch.bfloat16), haloed(res)      # keep the device tensors alive across the raw-pointer call
+        native.check("conv", lib.rt_conv2d_nhwc(xh.data_ptr(), wp.data_ptr(), bd.data_ptr(), rh.data_ptr(),
+                                                y.data_ptr(), B, H, W, Cin, Cout, ks, stride, up, 0, st))
+        got = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
+        assert rel_l2(got, ref + res) < 4e-3, (ks, stride, up)
+        assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0    # halo untouched
+
+
+def test_vae_decode(vae_pair, gpu):
+    p, vae = vae_pair
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 16, 16, 16, generator=g).to(torch.bfloat16).float()
+    ref = vorc.decode(p, VAE_SMALL, z)
+    out = vae.decode(z.to(gpu, torch.bfloat16), return_dict=False)[0]
+    err = rel_l2(out.float().cpu(), ref)
+    print(f"vae decode rel-L2 {err:.3e}")
+    assert err < 3e-2          # ~40 bf16-stored layers incl. GroupNorms
+    # packed fast path: unpack + z/scaling + shift fused, uint8 out
+    lat = ((z - 0.1159) * 0.3611).to(torch.bfloat16)
+    packed = orc.pack_latents(lat.float()).to(gpu, torch.bfloat16)
+    u8 = vae.decode_packed(packed, 16, 16, output_u8=True)
+    ref_u8 = ((ref / 2 + 0.5).clamp(0, 1) * 255).round().permute(0, 2, 3, 1)
+    diff = (u8.float().cpu() - ref_u8).abs()
+    print(f"vae u8 mean abs diff {float(diff.mean()):.3f} max {float(diff.max()):.0f}")
+    assert float(diff.mean()) < 2.0
+
+
+def test_vae_encode(vae_pair, gpu):
+    p, vae = vae_pair
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    mean, logvar = vorc.encode_moments(p, VAE_SMALL, x)
+    dist = vae.encode(x.to(gpu, torch.bfloat16)).latent_dist
+    e1, e2 = rel_l2(dist.mean.float().cpu(), mean), rel_l2(dist.logvar.float().cpu(), logvar)
+    print(f"vae encode rel-L2 mean {e1:.3e} logvar {e2:.3e}")
+    assert e1 < 3e-2 and e2 < 3e-2
+    gen = torch.Generator().manual_seed(7)
+    s = dist.sample(gen)
+    noise = torch.randn(mean.shape, generator=torch.Generator().manual_seed(7), dtype=torch.bfloat16).float()
+    assert rel_l2(s.float().cpu(), vorc.sample_latents(mean, logvar, noise)) < 3e-2
+
+
+def test_pipeline_c1_latents_and_image(vae_pair, gpu):
+    """BASELINE config C1 shape (256x256, 2 steps, one glyph line) through FluxControlNetPipeline.__call__ with
+    output_type='latent' (the parity tap, PIPE:1132-1133) against the oracle's denoise loop."""
+    from PIL import Image
+
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    p_vae, vae = vae_pair
+    tp = orc.init_mmdit_params(SMALL_T, seed=11)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=12, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    H = W = 256
+    N, T = 256, 64
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    pe, pooled, hint = r(1, T, 256), r(1, 64), r(1, N, 128)
+    noise = r(1, 16, 32, 32)
+    lat0 = orc.pack_latents(noise)
+    mask_np = np.zeros([H, W], dtype=np.uint8)
+    mask_np[60:140, 80:200] = 255
+    mask_img = Image.fromarray(mask_np)
+    rm = torch.nn.functional.interpolate(torch.from_numpy(mask_np)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1)
+    sig = orc.flow_sigmas(2, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    assert abs(float(sig[1]) - 0.622459) < 1e-5
+    ref = orc.denoise_loop(tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, [hint], [rm], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
+    out = pipe(prompt_embeds=pe.to(gpu, torch.bfloat16), pooled_prompt_embeds=pooled.to(gpu, torch.bfloat16), height=H, width=W,
+               num_inference_steps=2, guidance_scale=3.5, control_image=[hint.to(gpu, torch.bfloat16)], control_mask=[mask_img],
+               controlnet_conditioning_scale=1.0, controlnet_conditioning_step=30, latents=lat0.to(gpu, torch.bfloat16),
+               output_type="latent").images
+    err = rel_l2(out.float().cpu(), ref)
+    print(f"C1-shape pipeline latents rel-L2 {err:.3e}")
+    assert err < 2e-2
+    # zero-initialised tower == plain FLUX through the whole pipeline
+    cn.zero_init_controlnet_()
+    ref0 = orc.denoise_loop(tp, SMALL_T, None, None, lat0, pe, pooled, [], [], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
+    out0 = pipe(prompt_embeds=pe.to(gpu, torch.bfloat16), pooled_prompt_embeds=pooled.to(gpu, torch.bfloat16), height=H, width=W,
+                num_inference_steps=2, guidance_scale=3.5, control_image=[hint.to(gpu, torch.bfloat16)], control_mask=[mask_img],
+                latents=lat0.to(gpu, torch.bfloat16), output_type="latent").images
+    assert rel_l2(out0.float().cpu(), ref0) < 2e-2
+    # full call to PIL through the VAE decoder
+    img = pipe(prompt_embeds=pe.to(gpu, torch.bfloat16), pooled_prompt_embeds=pooled.to(gpu, torch.bfloat16), height=H, width=W,
+               num_inference_steps=2, guidance_scale=3.5, control_image=[hint.to(gpu, torch.bfloat16)], control_mask=[mask_img],
+               latents=lat0.to(gpu, torch.bfloat16)).images[0]
+    assert img.size == (256, 256)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe.to(gpu), height=250, width=256)        # PIPE:496
