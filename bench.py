@@ -110,12 +110,26 @@ class GemmTimer:
         return len(self.events), sum(self.flops), tot_ms * 1e-3
 
 
+def usable_cores() -> int:
+    """Cores this process may actually run on: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but grants a 16-CPU share; running 256 threads there oversubscribes 16x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("RT_CPU_BASELINE_THREADS", "16"))))
+
+
 def cpu_baseline(cfg_t, H, W, steps, lines, cfg_c, budget_s=12.0):
     """Oracle (fp32 torch CPU ops) on a bounded sample: whole MMDiT blocks at the C2 sequence length, extrapolated by
     block count to one image. Returns the cpu_baseline JSON object."""
     from oracle import flux_oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     d = cfg_t["num_attention_heads"] * cfg_t["attention_head_dim"]
     T, N = 512, (H // 16) * (W // 16)

@@ -336,7 +336,7 @@ def init_mmdit_params(cfg: dict, seed: int, controlnet: bool = False, bias_std: 
         _lin(p, "controlnet_x_embedder", d, cfg["in_channels"] + cfg.get("extra_condition_channels", 0), g, bias_std=bias_std)
     else:
         _lin(p, "norm_out.linear", 2 * d, d, g, bias_std=bias_std)
-        _lin(p, "proj_out", cfg.get("out_channels", cfg["in_channels"]), d, g, bias_std=bias_std)
+        _lin(p, "proj_out", cfg.get("out_channels") or cfg["in_channels"], d, g, bias_std=bias_std)
     if round_bf16:
         for k in p:
             p[k] = p[k].to(torch.bfloat16).to(torch.float32)
