@@ -17,6 +17,9 @@
 // Reference math: torch.nn.functional.linear as reached from controlnet_flux.py:277,280,292,386,391 and the
 // diffusers blocks; epilogue terms documented in include/reptext_hip.h.
 #include "rt_common.h"
+#include <stdlib.h>
+#include <initializer_list>
+#include <type_traits>
 
 namespace {
 
@@ -35,51 +38,97 @@ struct Launch {
   int ngroups;
 };
 
-template <bool OUT_F32, typename GT>
-__device__ __forceinline__ void epilogue_store(const GT& g, int bidx, int m, int n, f32x4 v) {
-  // v holds columns n..n+3 of row m. All optional terms are wave-uniform branches.
-  if (g.bias) {
-    const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.bias) + n);
-    v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
-  }
-  if (n >= g.gelu_from) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
-  }
+// Epilogue for one wave: 8x4 accumulator fragments -> C. Lane owns rows mrow + 16i (i<8) and, per fragment column j,
+// the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the 4 fragment columns;
+// per-row terms (residual, add2) are fetched one row ahead of the row being finished, so no store waits on a load.
+template <bool OUT_F32>
+__device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[8][4]) {
   const int rpb = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
-  if (g.gate) {
-    const int gb = bidx * (g.M / rpb) + m / rpb;
-    const f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)gb * g.gate_ld + n);
-    v *= gt;
-  }
-  v *= g.alpha;
-  if (g.rowscale) v *= g.rowscale[m % rpb];
-  const int64_t coff = (int64_t)bidx * g.strideC + (int64_t)m * g.ldc + n;
-  if (g.res) {
-    const int64_t roff = (int64_t)bidx * g.strideR + (int64_t)m * g.ldr + n;
-    if (OUT_F32) {
-      v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.res) + roff);
-    } else {
-      const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.res) + roff);
-      v[0] += bf16lo(r[0]); v[1] += bf16hi(r[0]); v[2] += bf16lo(r[1]); v[3] += bf16hi(r[1]);
+  bool nok[4];
+  f32x4 bias4[4], gate4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = ncol + 16 * j;
+    nok[j] = n < g.N;
+    const int nc = nok[j] ? n : 0;                    // clamp: masked columns read column 0, never stored
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.bias) + nc);
+      bias4[j] = f32x4{bf16lo(b[0]), bf16hi(b[0]), bf16lo(b[1]), bf16hi(b[1])};
     }
   }
-  if (g.add2) {
-    const int64_t aoff = (int64_t)bidx * g.stride2 + (int64_t)m * g.ld2 + n;
-    const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.add2) + aoff);
-    v[0] += bf16lo(r[0]); v[1] += bf16hi(r[0]); v[2] += bf16lo(r[1]); v[3] += bf16hi(r[1]);
+  // gate depends on (batch, row / rpb): constant over the tile unless the tile straddles batch entries (rpb < M)
+  const bool gate_per_row = g.gate && (rpb < g.M);
+  if (g.gate && !gate_per_row) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      gate4[j] = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)bidx * g.gate_ld + (nok[j] ? ncol + 16 * j : 0));
   }
-  if (OUT_F32) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + coff) = v;
-  } else {
-    u32x2 o;
-    o[0] = pack_bf16x2(v[0], v[1]);
-    o[1] = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
+  typedef typename std::conditional<OUT_F32, f32x4, u32x2>::type res_t;
+  res_t rnext[4];
+  u32x2 anext[4];
+  auto fetch_row = [&](int i) {
+    const int m = min(mrow + 16 * i, g.M - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nc = nok[j] ? ncol + 16 * j : 0;
+      if (g.res) {
+        const int64_t roff = (int64_t)bidx * g.strideR + (int64_t)m * g.ldr + nc;
+        if (OUT_F32) rnext[j] = *reinterpret_cast<const res_t*>(reinterpret_cast<const float*>(g.res) + roff);
+        else rnext[j] = *reinterpret_cast<const res_t*>(reinterpret_cast<const bf16_t*>(g.res) + roff);
+      }
+      if (g.add2) anext[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.add2) + (int64_t)bidx * g.stride2 + (int64_t)m * g.ld2 + nc);
+    }
+  };
+  if (g.res || g.add2) fetch_row(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = mrow + 16 * i;
+    res_t rcur[4];
+    u32x2 acur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rcur[j] = rnext[j]; acur[j] = anext[j]; }
+    if ((g.res || g.add2) && i + 1 < 8) fetch_row(i + 1);
+    const int mc = min(m, g.M - 1);
+    const float rs = g.rowscale ? g.rowscale[mc % rpb] * g.alpha : g.alpha;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol + 16 * j;
+      f32x4 v = acc[i][j] + bias4[j];
+      if (n >= g.gelu_from) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+      }
+      if (g.gate) {
+        if (gate_per_row) {
+          const int gb = bidx * (g.M / rpb) + mc / rpb;
+          v *= *reinterpret_cast<const f32x4*>(g.gate + (int64_t)gb * g.gate_ld + (nok[j] ? n : 0));
+        } else {
+          v *= gate4[j];
+        }
+      }
+      v *= rs;
+      if (g.res) {
+        if constexpr (OUT_F32) v += rcur[j];
+        else { v[0] += bf16lo(rcur[j][0]); v[1] += bf16hi(rcur[j][0]); v[2] += bf16lo(rcur[j][1]); v[3] += bf16hi(rcur[j][1]); }
+      }
+      if (g.add2) { v[0] += bf16lo(acur[j][0]); v[1] += bf16hi(acur[j][0]); v[2] += bf16lo(acur[j][1]); v[3] += bf16hi(acur[j][1]); }
+      if (m < g.M && nok[j]) {
+        const int64_t coff = (int64_t)bidx * g.strideC + (int64_t)m * g.ldc + n;
+        if constexpr (OUT_F32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + coff) = v;
+        } else {
+          u32x2 o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
+        }
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
+__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_simple_kernel(const Launch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- which problem / tile is this workgroup? (scalar)
@@ -179,20 +228,180 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
   // ---- epilogue: lane owns row m = ... + l15 and columns n = ... + 4*(lane>>4) .. +3 of each fragment
   const int mrow = m0 + wm * 128 + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
+  if (g.out_f32) epilogue_tile<true>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false>(g, bidx, mrow, ncol, acc);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong variant (default). Same tile, LDS image and MFMA mapping as the simple kernel, different schedule:
+//   * a K-tile is consumed in 4 phases of 16 MFMAs, one quadrant of the wave's 128x64 output each, in the order
+//     (a0,b0) (a0,b1) (a1,b1) (a1,b0) so only 12+4+8+0 fragment reads are needed per K-tile;
+//   * waves 4-7 run one barrier behind waves 0-3, so of the two waves that share a SIMD one is in its MFMA cluster
+//     while the other reads fragments / issues LDS-DMA: the matrix pipe always has a wave feeding it;
+//   * the operand parts a0,b0,b1,a1 of tile t+1 are issued (2 LDS-DMA per wave) in phases 1..4 of tile t and
+//     consumed in the same order one tile later; they stay in flight ACROSS the barriers behind a counted
+//     s_waitcnt vmcnt(4) (never 0 in steady state). Each wait sits before the barrier that precedes the MFMA
+//     cluster, i.e. one barrier earlier than the first read of that data by EITHER wave group (the staggered group
+//     reads one barrier later), which is what orders LDS-DMA writes for other waves' ds_reads.
+// ---------------------------------------------------------------------------------------------------
+#define RT_BAR()                              \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+#define RT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
+  LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)L;
+  int gi = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = mrow + i * 16;
-    if (m < g.M) {
+  for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
+    if (i < Lp->ngroups && (int)blockIdx.x >= Lp->grp[i].tile_begin) gi = i;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GroupDev G = Lp->grp[gi];
+#else
+  const GroupDev G = L.grp[0];
+#endif
+  const rt_gemm_group& g = G.g;
+  int t = (int)blockIdx.x - G.tile_begin;
+  const int tiles_per_batch = G.tiles_m * G.tiles_n;
+  const int bidx = t / tiles_per_batch;
+  t -= bidx * tiles_per_batch;
+  const int tn = t / G.tiles_m;
+  const int tm = t - tn * G.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- staging: part 0 = a0, 1 = b0, 2 = b1, 3 = a1; each wave stages 16 rows (2 pieces of 8) of every part.
+  //      a-part rows r' in [0,128): tile row = r' + 64*ah + (r' >= 64 ? 64 : 0)      (rows of both wave rows' half ah)
+  //      b-part rows r' in [0,128): tile row = (r'/32)*64 + 32*bh + r'%32            (rows of all four wave cols' half bh)
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)bidx * g.strideA;
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  uint32_t src[4][2];     // element offsets from Ab / Wb (both tensors are < 2^31 elements)
+  int lds_off[4][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = ncol + j * 16;
-        if (n < g.N) {
-          if (g.out_f32) epilogue_store<true>(g, bidx, m, n, acc[i][j]);
-          else epilogue_store<false>(g, bidx, m, n, acc[i][j]);
-        }
+  for (int part = 0; part < 4; ++part) {
+    const bool is_a = (part == 0 || part == 3);
+    const int half = (part == 2 || part == 3) ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int rowbase;   // wave-uniform first row of this 8-row piece inside its operand tile
+      if (is_a) rowbase = wave * 16 + q * 8 + 64 * half + (wave >= 4 ? 64 : 0);
+      else rowbase = (wave >> 1) * 64 + 32 * half + (wave & 1) * 16 + q * 8;
+      const int row = rowbase + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      if (is_a) {
+        const int am = min(m0 + row, g.M - 1);
+        src[part][q] = (uint32_t)((int64_t)am * g.lda + lc * 8);
+        lds_off[part][q] = rowbase * 128;
+      } else {
+        const int wr = min(n0 + row, g.N - 1);
+        src[part][q] = (uint32_t)((int64_t)wr * g.ldw + lc * 8);
+        lds_off[part][q] = TILE_BYTES + rowbase * 128;
       }
     }
   }
+  auto issue = [&](int part, int buf, int koff) {
+    const bf16_t* base = ((part == 0 || part == 3) ? Ab : Wb) + koff;     // wave-uniform (SGPR) base + per-lane 32-bit offset
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(base + src[part][q]), LDS_PTR(smem + buf * BUF_BYTES + lds_off[part][q]), 16, 0, 0);
+  };
+
+  const int l15 = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
+  const int a_base = wm * 128 * 128;
+  const int w_base = TILE_BYTES + wn * 64 * 128;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2];        // current a-half: [frag][kk]
+  bf16x8 wf[2][2][2];     // both b-halves: [half][frag][kk]
+
+#define RT_READ_A(ah)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*4 + i) * 2048 + rd0);                          \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*4 + i) * 2048 + rd1);                          \
+  }
+#define RT_READ_B(bh)                                                                                             \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
+    wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd0);                      \
+    wf[bh][j][1] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd1);                      \
+  }
+#define RT_MFMA(ah, bh)                                                                                           \
+  do {                                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+          acc[(ah)*4 + i][(bh)*2 + j] =                                                                           \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+  } while (0)
+
+  const int nk = g.K / BK;
+  issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0); issue(3, 0, 0);
+  RT_VMCNT(4);
+  RT_BAR();
+  if (wm == 1) RT_BAR();                       // stagger waves 4-7 by one barrier
+
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* tb = smem + (kt & 1) * BUF_BYTES;
+    const int nb = (kt & 1) ^ 1;
+    const int koff = (kt + 1) * BK;
+    // ---- phase 1: (a0,b0)
+    RT_READ_A(0); RT_READ_B(0);
+    issue(0, nb, koff);
+    RT_VMCNT(4);                               // b1(kt) landed (younger: a1(kt), a0(kt+1))
+    RT_BAR(); RT_MFMA(0, 0); RT_BAR();
+    // ---- phase 2: (a0,b1)
+    RT_READ_B(1);
+    issue(1, nb, koff);
+    RT_VMCNT(4);                               // a1(kt) landed (younger: a0(kt+1), b0(kt+1))
+    RT_BAR(); RT_MFMA(0, 1); RT_BAR();
+    // ---- phase 3: (a1,b1)
+    RT_READ_A(1);
+    issue(2, nb, koff);
+    RT_BAR(); RT_MFMA(1, 1); RT_BAR();
+    // ---- phase 4: (a1,b0)  (b0 still in registers)
+    issue(3, nb, koff);
+    RT_VMCNT(4);                               // a0(kt+1), b0(kt+1) landed (younger: b1(kt+1), a1(kt+1))
+    RT_BAR(); RT_MFMA(1, 0); RT_BAR();
+  }
+  {                                            // last K-tile: nothing left to issue, drain
+    const char* tb = smem + ((nk - 1) & 1) * BUF_BYTES;
+    RT_READ_A(0); RT_READ_B(0);
+    RT_VMCNT(0);
+    RT_BAR(); RT_MFMA(0, 0); RT_BAR();
+    RT_READ_B(1);
+    RT_BAR(); RT_MFMA(0, 1); RT_BAR();
+    RT_READ_A(1);
+    RT_BAR(); RT_MFMA(1, 1); RT_BAR();
+    RT_BAR(); RT_MFMA(1, 0); RT_BAR();
+  }
+  if (wm == 0) RT_BAR();                       // balance the stagger barrier
+#undef RT_READ_A
+#undef RT_READ_B
+#undef RT_MFMA
+
+  const int mrow = m0 + wm * 128 + l15;
+  const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
+  if (g.out_f32) epilogue_tile<true>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false>(g, bidx, mrow, ncol, acc);
 }
 
 }  // namespace
@@ -221,13 +430,16 @@ extern "C" int rt_gemm_bf16(const rt_gemm_group* groups, int32_t ngroups, void* 
     L.grp[i].tile_begin = total;
     total += L.grp[i].tiles_m * L.grp[i].tiles_n * g.batch;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  static int variant = -1;   // RT_GEMM_VARIANT=simple selects the 2-phase reference schedule (A/B and debugging)
+  if (variant < 0) {
+    const char* v = getenv("RT_GEMM_VARIANT");
+    variant = (v && v[0] == 's') ? 0 : 1;
+    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16_kernel), reinterpret_cast<const void*>(gemm_bf16_simple_kernel)}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  if (variant == 0) hipLaunchKernelGGL(gemm_bf16_simple_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  else hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
   return rt_hip_status();
 }

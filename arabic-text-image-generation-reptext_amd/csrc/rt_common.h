@@ -33,8 +33,11 @@ __device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u &
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // GELU tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))  == x * sigmoid(2u)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  // x·sigmoid(2u), u = sqrt(2/pi)(x + 0.044715x³); exp and reciprocal on the transcendental unit (v_exp_f32, v_rcp_f32):
+  // ~8 VALU ops per element instead of ~25 for __expf + IEEE divide. |rel err| < 4e-7.
+  const float x2 = x * x;
+  const float t = x * (-2.302208198f - 0.1029432397f * x2);     // -2u·log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
