@@ -258,22 +258,34 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
   typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
   LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
   (void)L;
+  // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so
+  // blocks b and b+8 share an L2. Remap so each XCD owns a CONTIGUOUS run of the tile order (bijective for any grid
+  // size), then walk each problem in panels of 8 tile-columns, row by row: the 32 tiles an XCD runs at a time form
+  // a ~4x8 patch that shares 4 A row-panels and 8 W row-panels in that XCD's L2 instead of ~9 and ~14.
+  const int nwg = (int)gridDim.x;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
   int gi = 0;
 #pragma unroll
   for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
-    if (i < Lp->ngroups && (int)blockIdx.x >= Lp->grp[i].tile_begin) gi = i;
+    if (i < Lp->ngroups && lin >= Lp->grp[i].tile_begin) gi = i;
 #if defined(__HIP_DEVICE_COMPILE__)
   const GroupDev G = Lp->grp[gi];
 #else
   const GroupDev G = L.grp[0];
 #endif
   const rt_gemm_group& g = G.g;
-  int t = (int)blockIdx.x - G.tile_begin;
+  int t = lin - G.tile_begin;
   const int tiles_per_batch = G.tiles_m * G.tiles_n;
   const int bidx = t / tiles_per_batch;
   t -= bidx * tiles_per_batch;
-  const int tn = t / G.tiles_m;
-  const int tm = t - tn * G.tiles_m;
+  constexpr int PANEL = 8;
+  const int panel = t / (PANEL * G.tiles_m);
+  const int pw = min(PANEL, G.tiles_n - panel * PANEL);          // width of this (possibly last, narrower) panel
+  const int tp = t - panel * PANEL * G.tiles_m;
+  const int tm = tp / pw;
+  const int tn = panel * PANEL + (tp - tm * pw);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x;

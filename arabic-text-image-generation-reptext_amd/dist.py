@@ -46,19 +46,18 @@ def _flatten(c: Conditioning, dtype) -> torch.Tensor:
 
 def broadcast_conditioning(c: Optional[Conditioning], spec: Sequence[Tuple[str, Tuple[int, ...]]], device, src: int = 0,
                            dtype=torch.bfloat16, mask_dtype=torch.float32) -> Conditioning:
-    """One `dist.broadcast` of a flat buffer (bf16 payload; masks are 0..1 values, exact enough in bf16? no — masks are
-    sent in the same buffer but scaled to integers /255 on the sender, see below). Non-source ranks pass c=None and the
-    static `spec` (names + shapes) that all ranks agree on.
+    """ONE `dist.broadcast` of a flat fp32 buffer holding every conditioning tensor back to back.
 
-    Payload at C2 with one text line: 512·4096 + 768 + 4096·128 + 4096 elements ≈ 5 MiB in bf16."""
+    Non-source ranks pass ``c=None`` and the static ``spec`` (names + shapes) all ranks agree on. fp32 on the wire keeps
+    the bilinear regional masks exact (bf16 would round them); embeddings/hints are bf16 values, so they survive the
+    round trip bit-exactly. Payload at C2 with one text line: (512*4096 + 768 + 4096*128 + 4096) * 4 B ~ 10 MiB —
+    latency-bound on xGMI, issued once per prompt."""
     n = sum(int(torch.tensor(s).prod()) for _, s in spec)
     if dist.get_rank() == src:
         if c is None:
             raise ValueError("source rank must provide the conditioning")
         if [tuple(s) for _, s in c.spec()] != [tuple(s) for _, s in spec]:
             raise ValueError("conditioning does not match the agreed spec")
-        # masks are bilinear-downsampled 0..1 values; bf16 would round them, so the whole buffer travels as fp32 when any
-        # mask is present. 10 MiB instead of 5 MiB — still latency-bound on xGMI.
         flat = _flatten(c, torch.float32).to(device)
     else:
         flat = torch.empty(n, device=device, dtype=torch.float32)

@@ -1,0 +1,169 @@
+"""CPU tests of the host-side mirror of the reference interface: signatures, error behaviour, schedule, state-dict
+layout, checkpoint IO, drop-in module names. No kernels run here."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flux_oracle as orc
+from oracle import vae_oracle as vorc
+
+SMALL_T = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=1,
+               joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+SMALL_CN = dict(SMALL_T, num_single_layers=0, extra_condition_channels=64)
+
+
+def test_dropin_module_names_and_call_signature():
+    """infer.py:2-3 / infer_inpaint.py:3-4 import lines and the kwargs infer.py:117-130 passes."""
+    from controlnet_flux import FluxControlNetModel, FluxControlNetOutput, FluxMultiControlNetModel  # noqa: F401
+    from pipeline_flux_controlnet import FluxControlNetPipeline
+
+    sig = inspect.signature(FluxControlNetPipeline.__call__)
+    expected = ["prompt", "prompt_2", "height", "width", "num_inference_steps", "timesteps", "guidance_scale", "control_guidance_start",
+                "control_guidance_end", "control_image", "control_mode", "controlnet_conditioning_scale", "controlnet_conditioning_step",
+                "num_images_per_prompt", "generator", "latents", "prompt_embeds", "pooled_prompt_embeds", "output_type", "return_dict",
+                "joint_attention_kwargs", "callback_on_step_end", "callback_on_step_end_tensor_inputs", "max_sequence_length",
+                "control_mask", "control_position", "control_glyph"]
+    assert list(sig.parameters)[1:] == expected                                      # PIPE:751-781 order
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["num_inference_steps"] == 28 and d["guidance_scale"] == 7.0 and d["controlnet_conditioning_step"] == 30   # Q10
+    assert d["output_type"] == "pil" and d["max_sequence_length"] == 512
+    fsig = inspect.signature(FluxControlNetModel.forward)
+    assert list(fsig.parameters)[1:13] == ["hidden_states", "controlnet_cond", "controlnet_mode", "conditioning_scale", "encoder_hidden_states",
+                                            "pooled_projections", "timestep", "img_ids", "txt_ids", "guidance", "joint_attention_kwargs",
+                                            "return_dict"]                           # CN:216-230
+    csig = inspect.signature(FluxControlNetModel.__init__)
+    assert csig.parameters["num_layers"].default == 19 and csig.parameters["num_single_layers"].default == 38   # CN:49-50
+    assert csig.parameters["guidance_embeds"].default is False and csig.parameters["extra_condition_channels"].default == 0
+
+
+def test_state_dict_keys_match_diffusers_layout_and_counts():
+    from reptext_amd.config import flux_dev_transformer_config, reptext_controlnet_config
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.transformer import FluxTransformer2DModel
+    from reptext_amd.vae import AutoencoderKL
+
+    tr = FluxTransformer2DModel(**SMALL_T, device="cpu", dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device="cpu", dtype=torch.bfloat16)
+    assert set(tr.state_dict()) == set(orc.init_mmdit_params(SMALL_T, 0))
+    assert set(cn.state_dict()) == set(orc.init_mmdit_params(SMALL_CN, 0, controlnet=True))
+    vcfg = dict(vorc.FLUX_VAE_CFG, block_out_channels=(32, 32, 64, 64))
+    vae = AutoencoderKL(**vcfg, device="cpu", dtype=torch.bfloat16)
+    assert set(vae.state_dict()) == set(vorc.init_vae_params(vcfg, 0))
+    count = lambda cls, cfg: sum(p.numel() for p in cls(**cfg, device="meta", dtype=torch.bfloat16).parameters())
+    assert count(FluxTransformer2DModel, flux_dev_transformer_config()) == 11_901_408_320
+    assert abs(count(FluxControlNetModel, reptext_controlnet_config()) / 1e9 - 2.1411) < 5e-4
+
+
+def test_checkpoint_roundtrip_local_dir(tmp_path):
+    from reptext_amd.controlnet import FluxControlNetModel
+
+    cn = FluxControlNetModel(**SMALL_CN, device="cpu", dtype=torch.bfloat16)
+    cn.load_state_dict(orc.init_mmdit_params(SMALL_CN, 3, controlnet=True))
+    cn.save_pretrained(str(tmp_path / "cn"))
+    cn2 = FluxControlNetModel.from_pretrained(str(tmp_path / "cn"), torch_dtype=torch.bfloat16)
+    assert cn2.config.extra_condition_channels == 64 and cn2.config.num_layers == 1
+    for (k, a), (_, b) in zip(sorted(cn.state_dict().items()), sorted(cn2.state_dict().items())):
+        assert torch.equal(a, b), k
+    with pytest.raises(OSError):
+        FluxControlNetModel.from_pretrained("Shakker-Labs/RepText", torch_dtype=torch.bfloat16)     # hub id: offline -> loud error
+
+
+def _cpu_pipe():
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+    from reptext_amd.vae import AutoencoderKL
+
+    tr = FluxTransformer2DModel(**SMALL_T, device="cpu", dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device="cpu", dtype=torch.bfloat16)
+    vae = AutoencoderKL(**dict(vorc.FLUX_VAE_CFG, block_out_channels=(32, 32, 64, 64)), device="cpu", dtype=torch.bfloat16)
+    return FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+
+
+def test_pipeline_host_helpers_and_errors():
+    pipe = _cpu_pipe()
+    assert pipe.vae_scale_factor == 16 and pipe.default_sample_size == 64 and pipe.tokenizer_max_length == 77       # PIPE:219-226
+    pe = torch.zeros(1, 8, 64)
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe.check_inputs(None, None, 250, 256, prompt_embeds=pe, pooled_prompt_embeds=pe)
+    with pytest.raises(ValueError, match="Cannot forward both"):
+        pipe.check_inputs("a", None, 256, 256, prompt_embeds=pe, pooled_prompt_embeds=pe)
+    with pytest.raises(ValueError, match="Provide either"):
+        pipe.check_inputs(None, None, 256, 256)
+    with pytest.raises(ValueError, match="pooled_prompt_embeds"):
+        pipe.check_inputs(None, None, 256, 256, prompt_embeds=pe)
+    with pytest.raises(ValueError, match="max_sequence_length"):
+        pipe.check_inputs("a", None, 256, 256, max_sequence_length=513)
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe.check_inputs("a", None, 256, 256, callback_on_step_end_tensor_inputs=["nope"])
+    with pytest.raises(ValueError, match="without text encoders"):
+        pipe.encode_prompt("a street sign", None)
+    x = torch.randn(2, 16, 8, 12)
+    packed = pipe._pack_latents(x, 2, 16, 8, 12)
+    assert torch.equal(packed, orc.pack_latents(x))
+    assert torch.equal(pipe._unpack_latents(packed, 64, 96, 16), x)
+    assert torch.equal(pipe._prepare_latent_image_ids(1, 8, 12, "cpu", torch.float32), orc.latent_image_ids(8, 12))
+    lat, ids = pipe.prepare_latents(2, 16, 128, 192, torch.float32, "cpu", torch.Generator().manual_seed(0))
+    assert lat.shape == (2, 8 * 12, 64) and ids.shape == (96, 3)
+    with pytest.raises(ValueError, match="list of generators"):
+        pipe.prepare_latents(2, 16, 128, 192, torch.float32, "cpu", [torch.Generator()])
+    from PIL import Image
+
+    m = np.zeros([64, 64], dtype=np.uint8); m[16:48, 16:48] = 255
+    masks = pipe._region_masks([Image.fromarray(m)], "cpu", torch.float32)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(m)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1)
+    assert torch.equal(masks[0], ref) and masks[0].shape == (1, 16, 1)
+    # the hot path itself refuses to run on CPU (no fallback)
+    with pytest.raises(RuntimeError):
+        pipe(prompt_embeds=torch.zeros(1, 8, 64, dtype=torch.bfloat16), pooled_prompt_embeds=torch.zeros(1, 32, dtype=torch.bfloat16),
+             height=64, width=64, num_inference_steps=1, control_image=[torch.zeros(1, 16, 128, dtype=torch.bfloat16)], output_type="latent")
+
+
+def test_scheduler_matches_known_schedule_and_reference_call_pattern():
+    from reptext_amd.pipeline import retrieve_timesteps
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler, calculate_shift
+
+    s = FlowMatchEulerDiscreteScheduler()
+    mu = calculate_shift(4096, s.config.base_image_seq_len, s.config.max_image_seq_len, s.config.base_shift, s.config.max_shift)
+    assert abs(mu - 1.15) < 1e-12 and abs(calculate_shift(4096) - 1.16) < 1e-12
+    ts, n = retrieve_timesteps(s, 28, "cpu", None, np.linspace(1.0, 1 / 28, 28), mu=mu)
+    assert n == 28 and s.order == 1 and torch.allclose(s.sigmas, orc.flow_sigmas(28, 1.15), atol=1e-7)
+    assert torch.allclose(ts, s.sigmas[:-1] * 1000)
+    with pytest.raises(ValueError, match="Only one of"):
+        retrieve_timesteps(s, 28, "cpu", [1.0], [1.0], mu=mu)
+    with pytest.raises(ValueError, match="mu"):
+        s.set_timesteps(4)
+
+
+def test_image_processor():
+    from PIL import Image
+
+    from reptext_amd.image_processor import VaeImageProcessor
+
+    ip = VaeImageProcessor(vae_scale_factor=16)
+    img = Image.fromarray((np.arange(64 * 64 * 3) % 256).astype(np.uint8).reshape(64, 64, 3))
+    x = ip.preprocess(img, height=64, width=64)
+    assert x.shape == (1, 3, 64, 64) and float(x.min()) >= -1 and float(x.max()) <= 1
+    assert abs(float(x[0, 0, 0, 0]) - (2 * 0 / 255 - 1)) < 1e-6
+    g = ip.preprocess(Image.fromarray(np.full((32, 32), 255, np.uint8)), height=64, width=64)
+    assert g.shape == (1, 1, 64, 64) and float(g.min()) > 0.99
+    u8 = torch.randint(0, 255, (2, 8, 8, 3), dtype=torch.uint8)
+    pil = ip.postprocess_u8(u8, "pil")
+    assert len(pil) == 2 and pil[0].size == (8, 8)
+    assert np.allclose(ip.postprocess_u8(u8, "np"), u8.numpy() / 255.0)
+
+
+def test_randn_tensor_device_rule():
+    from reptext_amd.utils import randn_tensor
+
+    a = randn_tensor((2, 4), torch.Generator().manual_seed(1), "cpu", torch.float32)
+    b = torch.randn((2, 4), generator=torch.Generator().manual_seed(1))
+    assert torch.equal(a, b)
+    c = randn_tensor((2, 4), [torch.Generator().manual_seed(1), torch.Generator().manual_seed(2)], "cpu", torch.float32)
+    assert torch.equal(c[1:], torch.randn((1, 4), generator=torch.Generator().manual_seed(2)))
+    with pytest.raises(ValueError):
+        randn_tensor((3, 4), [torch.Generator()], "cpu", torch.float32)

@@ -1,0 +1,127 @@
+"""Pins the CPU oracle with the closed-form known answers of SURVEY.md §8c — the only pins that exist: the reference
+ships no tests or golden tensors for this path (parity unpinned; see oracle/__init__.py)."""
+import math
+
+import torch
+
+from oracle import flux_oracle as orc
+from oracle import vae_oracle as vorc
+
+C2_SIGMAS = [1.0, 0.988409, 0.976222, 0.963394, 0.949873, 0.935599, 0.920509, 0.904531, 0.887583, 0.869576, 0.850406, 0.829956,
+             0.808096, 0.784672, 0.759511, 0.732413, 0.703145, 0.671435, 0.636964, 0.599357, 0.558163, 0.512844, 0.462748,
+             0.407078, 0.344849, 0.274828, 0.195455, 0.104721, 0.0]
+
+
+def test_calculate_shift():
+    # scheduler config base/max shift 0.5/1.15, base/max seq 256/4096 (PIPE:952-958)
+    assert abs(orc.calculate_shift(4096, 256, 4096, 0.5, 1.15) - 1.15) < 1e-12
+    assert abs(orc.calculate_shift(256, 256, 4096, 0.5, 1.15) - 0.5) < 1e-12
+    assert abs(orc.calculate_shift(9216, 256, 4096, 0.5, 1.15) - 2.01667) < 1e-5
+    # function default max_shift is 1.16 (PIPE:83)
+    assert abs(orc.calculate_shift(4096) - 1.16) < 1e-12
+
+
+def test_sigma_schedules():
+    s1 = orc.flow_sigmas(2, 0.5)
+    assert torch.allclose(s1, torch.tensor([1.0, 0.622459, 0.0]), atol=1e-6)
+    s2 = orc.flow_sigmas(28, 1.15)
+    assert s2.dtype == torch.float32 and len(s2) == 29
+    assert torch.allclose(s2, torch.tensor(C2_SIGMAS), atol=1.5e-6)
+
+
+def test_pack_unpack_index_map_and_ids():
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    p = orc.pack_latents(x)
+    assert p.shape == (2, 6, 12)
+    for b in range(2):
+        for i in range(2):
+            for j in range(3):
+                for c in range(3):
+                    for dy in range(2):
+                        for dx in range(2):
+                            assert p[b, i * 3 + j, c * 4 + dy * 2 + dx] == x[b, c, 2 * i + dy, 2 * j + dx]
+    assert torch.equal(orc.unpack_latents(p, 2 * 16, 3 * 16, 16), x)
+    ids = orc.latent_image_ids(6, 8)          # latent 6x8 -> 3x4 tokens
+    assert ids.shape == (12, 3)
+    for r in range(3):
+        for c in range(4):
+            assert ids[r * 4 + c].tolist() == [0.0, float(r), float(c)]
+
+
+def test_interval_map_19_over_6():
+    assert orc.interval_map(19, 6) == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4]   # sample 5 never used (Q5)
+
+
+def _count(cfg, controlnet):
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    lin = lambda o, i: o * i + o
+    double = 2 * lin(6 * d, d) + 8 * lin(d, d) + 4 * 128 + 2 * (lin(4 * d, d) + lin(d, 4 * d))
+    single = lin(3 * d, d) + lin(4 * d, d) + lin(d, 5 * d) + 3 * lin(d, d) + 2 * 128
+    n = lin(d, 64) + lin(d, 4096) + (2 + (1 if cfg["guidance_embeds"] else 0) - 1) * 0
+    emb = (2 if cfg["guidance_embeds"] else 1) * (lin(d, 256) + lin(d, d)) + lin(d, 768) + lin(d, d)
+    n += emb + cfg["num_layers"] * double + cfg["num_single_layers"] * single
+    if controlnet:
+        n += (cfg["num_layers"] + cfg["num_single_layers"]) * lin(d, d) + lin(d, 64 + cfg["extra_condition_channels"])
+    else:
+        n += lin(2 * d, d) + lin(64, d)
+    return double, single, n
+
+
+def test_parameter_counts():
+    double, single, total = _count(orc.FLUX_DEV_CFG, False)
+    assert double == 339_831_296 and single == 141_591_808 and total == 11_901_408_320
+    _, _, cn = _count(orc.REPTEXT_CN_CFG, True)
+    assert abs(cn / 1e9 - 2.1411) < 5e-4 and abs(cn * 2 / 1e9 - 4.282) < 1e-3      # 4.28 GB checkpoint (NB:419)
+    small = dict(orc.FLUX_DEV_CFG, num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=4096)
+    p = orc.init_mmdit_params(dict(small), 0)
+    d = 256
+    assert p["transformer_blocks.0.norm1.linear.weight"].shape == (6 * d, d)
+    assert p["single_transformer_blocks.0.proj_out.weight"].shape == (d, 5 * d)
+
+
+def test_rope_and_timestep_conventions():
+    ids = torch.tensor([[0.0, 0.0, 0.0], [0.0, 3.0, 5.0]])
+    cos, sin = orc.rope_table(ids)
+    assert cos.shape == (2, 128) and torch.all(cos[0] == 1) and torch.all(sin[0] == 0)      # text ids -> identity rotation
+    assert torch.equal(cos[1, 0::2], cos[1, 1::2])                                             # each frequency repeated twice
+    assert abs(float(cos[1, 16]) - math.cos(3.0)) < 1e-6 and abs(float(sin[1, 16 + 56]) - math.sin(5.0)) < 1e-6
+    x = torch.randn(1, 2, 1, 128)
+    y = orc.apply_rope(x, cos, sin)
+    assert torch.allclose(y[0, 0], x[0, 0])
+    assert abs(float(y[0, 1, 0, 16]) - float(x[0, 1, 0, 16] * math.cos(3.0) - x[0, 1, 0, 17] * math.sin(3.0))) < 1e-5
+    e = orc.timestep_embedding(torch.tensor([0.0, 2.0]))
+    assert e.shape == (2, 256) and torch.all(e[0, :128] == 1) and torch.all(e[0, 128:] == 0)     # [cos | sin]
+    assert abs(float(e[1, 0]) - math.cos(2.0)) < 1e-6 and abs(float(e[1, 128]) - math.sin(2.0)) < 1e-6
+
+
+def test_zero_controlnet_equals_plain_flux_and_masking():
+    """§8c(6): zero-initialised zero-linears -> all-zero residuals -> identical transformer output (oracle level)."""
+    cfg_t = dict(orc.FLUX_DEV_CFG, num_layers=1, num_single_layers=1, num_attention_heads=1, joint_attention_dim=64, pooled_projection_dim=32)
+    cfg_c = dict(cfg_t, num_single_layers=0, extra_condition_channels=64)
+    tp, cp = orc.init_mmdit_params(cfg_t, 1), orc.init_mmdit_params(cfg_c, 2, controlnet=True)
+    for k in list(cp):
+        if k.startswith("controlnet_blocks"):
+            cp[k] = torch.zeros_like(cp[k])
+    g = torch.Generator().manual_seed(0)
+    N, T = 16, 8
+    lat, cond, pe, pooled = torch.randn(1, N, 64, generator=g), torch.randn(1, N, 128, generator=g), torch.randn(1, T, 64, generator=g), torch.randn(1, 32, generator=g)
+    ids, tids = orc.latent_image_ids(8, 8), torch.zeros(T, 3)
+    sig = orc.flow_sigmas(2, 0.5)
+    a = orc.denoise_loop(tp, cfg_t, cp, cfg_c, lat, pe, pooled, [cond], [None], sig, ids, tids, 3.5)
+    b = orc.denoise_loop(tp, cfg_t, None, None, lat, pe, pooled, [], [], sig, ids, tids, 3.5)
+    assert torch.allclose(a, b, atol=1e-6)
+    # conditioning_step = 0 disables the tower too (Q3)
+    cp2 = orc.init_mmdit_params(cfg_c, 2, controlnet=True)
+    c = orc.denoise_loop(tp, cfg_t, cp2, cfg_c, lat, pe, pooled, [cond], [None], sig, ids, tids, 3.5, conditioning_step=0)
+    assert torch.allclose(c, b, atol=1e-6)
+    d = orc.denoise_loop(tp, cfg_t, cp2, cfg_c, lat, pe, pooled, [cond], [torch.zeros(1, N, 1)], sig, ids, tids, 3.5)
+    assert torch.allclose(d, b, atol=1e-6)                                                     # an all-zero regional mask removes it
+
+
+def test_vae_oracle_shapes():
+    cfg = dict(vorc.FLUX_VAE_CFG, block_out_channels=(32, 32, 64, 64))
+    p = vorc.init_vae_params(cfg, 0)
+    img = vorc.decode(p, cfg, torch.randn(1, 16, 4, 4))
+    assert img.shape == (1, 3, 32, 32)
+    mean, logvar = vorc.encode_moments(p, cfg, torch.rand(1, 3, 32, 32) * 2 - 1)
+    assert mean.shape == (1, 16, 4, 4) and float(logvar.max()) <= 20.0
