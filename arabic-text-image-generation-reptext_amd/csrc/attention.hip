@@ -17,6 +17,8 @@
 // f(r) = ((r&3)<<2) | ((r>>2)&3): conflict-free for the row reads (K) and the transposed reads (V).
 // LDS-DMA writes lane-linear, so the XOR is applied to each lane's source address.
 #include "rt_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -25,13 +27,23 @@ constexpr int BQ = 128;       // query rows per workgroup
 constexpr int BKV = 64;       // keys per tile
 constexpr int TILE_B = BKV * DH * 2;   // 16 KiB
 constexpr int ATT_THREADS = 256;
+constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64 between rescales
 
 __device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-__device__ __forceinline__ s16x4 tr_read(const char* p) {
+// single-instruction 3-input max (fmaxf on MFMA outputs otherwise gets a canonicalising v_max in front of it)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+__device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+template <int ABL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* O,
     int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, int S, int H, float scale_log2) {
@@ -56,45 +68,70 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
-  // ---- staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V
+  // ---- staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V; K and V share row/chunk offsets.
   const int srow = lane >> 4;                 // row inside a piece
   const int spc = lane & 15;                  // physical chunk written by this lane
-  auto stage = [&](int slot, int kv0) {
+  int srow_t[4];                              // row inside the tile per piece
+  int soff[4];                                // element offset of (row, logical chunk) from the tile's first row
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    srow_t[p] = (wave * 4 + p) * 4 + srow;
+    soff[p] = srow_t[p] * (int)ld + ((spc ^ swz(srow_t[p])) << 3);
+  }
+  auto stage = [&](int slot, int kv0, bool clamp) {
     char* kb = smem + slot * 2 * TILE_B;
+    const bf16_t* kt0 = Kb + (int64_t)kv0 * ld;      // wave-uniform tile bases
+    const bf16_t* vt0 = Vb + (int64_t)kv0 * ld;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int r = (wave * 4 + p) * 4 + srow;          // row in tile
-      const int lc = spc ^ swz(r);                       // logical chunk to fetch
-      const int64_t grow = min(kv0 + r, S - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Kb + grow * ld + lc * 8), LDS_PTR(kb + (wave * 4 + p) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Vb + grow * ld + lc * 8), LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, 0, 0);
+      int off = soff[p];
+      if (clamp) off = min(kv0 + srow_t[p], S - 1) * (int)ld - kv0 * (int)ld + ((spc ^ swz(srow_t[p])) << 3);   // ragged last tile
+      __builtin_amdgcn_global_load_lds(GLB_PTR(kt0 + off), LDS_PTR(kb + (wave * 4 + p) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(vt0 + off), LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, 0, 0);
     }
   };
 
-  // ---- per-lane LDS read offsets
-  // K row read: row = 32kt + l31, chunk = 2ks + hh
-  int koff[2];
+  // ---- per-lane LDS read offsets (bytes inside a tile); everything that varies with (kt, ks, s, dt) statically is an
+  //      immediate, so the loop carries no address arithmetic.
+  // K row read: row = 32kt + l31, chunk = 2ks + hh  ->  l31*256 + ((2ks+hh) ^ swz(l31))*16  (+ kt*8192)
+  lds_cptr kp[8];                             // 32-bit LDS addresses; slot / kt offsets are immediates at the use site
+  {
+    const int ksw = swz(l31);                 // swz depends on row & 15 only
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) koff[kt] = (kt * 32 + l31) * 256;
-  const int ksw = swz(l31);                   // swz depends on row & 15 only; 32kt keeps it
-  // V transposed read: group g = lane>>4 (hh = g>>1), lane 4q+p supplies row r0+q, chunk c0+(p>>1), half p&1
+    for (int ks = 0; ks < 8; ++ks) kp[ks] = (lds_cptr)smem + (l31 * 256 + (((2 * ks + hh) ^ ksw) << 4));
+  }
+  // V transposed read: 16-lane group g = lane>>4 (hh = g>>1, d half g&1); lane 4q+p of the group supplies row r0+q,
+  // chunk c0+(p>>1), 8-byte half p&1. Rows: first block 4hh+tq, second block +8 (per k-step: + 32kt + 16s).
   const int tq = (lane >> 2) & 3, tp = lane & 3;
   const int tg1 = (lane >> 4) & 1;
+  lds_cptr vp[2][4];
+  {
+    const int cl = tg1 * 2 + (tp >> 1);
+    const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      vp[0][dt] = (lds_cptr)smem + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
+      vp[1][dt] = (lds_cptr)smem + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
+    }
+  }
 
   f32x16 o_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;     // running max (log2 domain, may lag the true max by <= RESCALE_THR) and row sum
 
   const int ntiles = (S + BKV - 1) / BKV;
-  stage(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); slot (t+1)&1 is free
-    if (t + 1 < ntiles) stage((t + 1) & 1, (t + 1) * BKV);
-    const char* kb = smem + (t & 1) * 2 * TILE_B;
-    const char* vb = kb + TILE_B;
+
+  auto tile = [&](auto slot_c, auto ragged_c, int t) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr bool RAGGED = decltype(ragged_c)::value;     // only the last tile of a sequence with S % 64 != 0
+    constexpr int SB = SLOT * 2 * TILE_B;
+    if (!(ABL & 2) || t == 0) {
+      __syncthreads();                         // tile t landed (vmcnt(0) + barrier); the other slot is free
+      if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * BKV, (t + 2) * BKV > S);
+    }
 
     // ---- Sᵀ = K·Qᵀ : two 32-key tiles
     f32x16 s_acc[2];
@@ -104,12 +141,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt] + (((2 * ks + hh) ^ ksw) << 4));
+        const bf16x8 kf = *(const __attribute__((address_space(3))) bf16x8*)(kp[ks] + SB + kt * 8192);
         s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kt], 0, 0, 0);
       }
     }
     // key of s_acc[kt][r]: 64t + 32kt + (r&3) + 8(r>>2) + 4hh
-    if ((t + 1) * BKV > S) {                   // ragged last tile: mask keys >= S (wave-uniform branch)
+    if constexpr (RAGGED) {                    // mask keys >= S
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -119,51 +156,77 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
         }
     }
 
-    // ---- online softmax (log2 domain); the row's other 32 keys live in lane ^ 32
-    float mx = s_acc[0][0];
+    // ---- online softmax in the log2 domain; the row's other 32 keys live in lane ^ 32.
+    float mx = 0.f;
+    if (!(ABL & 1)) {
+    mx = max3f(s_acc[0][0], s_acc[1][0], s_acc[0][1]);
+    mx = max3f(mx, s_acc[1][1], s_acc[0][2]);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int r = 3; r < 16; ++r) mx = max3f(mx, s_acc[0][r], s_acc[1][r - 1]);
+    mx = max3f(mx, s_acc[1][15], s_acc[1][14]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2;
+    }
+    // Deferred rescale: O and l are only rescaled when some row's max grew by more than RESCALE_THR (log2 units) over
+    // the max it is currently normalised with; otherwise P = exp2(s - m_run) <= 2^THR, harmless in fp32 accumulators
+    // and (being a relative format) in the bf16 P operand. The decision precedes every use of this tile's P.
+    if (__any(mx - m_run > RESCALE_THR)) {
+      asm volatile("" ::: "memory");           // keep this rare block a real branch (not if-converted into 64 multiplies)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0 on zeroed state
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * scale_log2);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float p = exp2f(s_acc[kt][8 * s + j] * scale_log2 - m_new);
-          psum += p;
-          pf[kt][s][j] = (__bf16)p;
+          float p;
+          if (ABL & 1) p = s_acc[kt][8 * s2 + j];
+          else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt][8 * s2 + j], scale_log2, -m_run));
+          if (!(ABL & 1)) psum += p;
+          pf[kt][s2][j] = (__bf16)p;
         }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    l_run += psum;
 
     // ---- Oᵀ += Vᵀ·Pᵀ : element j of lane-half hh of k-step (kt,s) is key 32kt + 16s + 8(j>>2) + 4hh + (j&3)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int r0 = kt * 32 + s * 16 + 4 * hh + tq;           // row this lane addresses (first 4-key block)
-        const int r1 = r0 + 8;                                    // second block
+      for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int ch = dt * 4 + tg1 * 2 + (tp >> 1);
-          const s16x4 lo = tr_read(vb + r0 * 256 + ((ch ^ swz(r0)) << 4) + 8 * (tp & 1));
-          const s16x4 hi = tr_read(vb + r1 * 256 + ((ch ^ swz(r1)) << 4) + 8 * (tp & 1));
+          const s16x4 lo = tr_read(vp[0][dt] + SB + kt * 8192 + s2 * 4096);
+          const s16x4 hi = tr_read(vp[1][dt] + SB + kt * 8192 + s2 * 4096);
           const bf16x8 vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi),
                                                     0, 1, 2, 3, 4, 5, 6, 7);
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s], o_acc[dt], 0, 0, 0);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], o_acc[dt], 0, 0, 0);
         }
       }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int nfull = S / BKV;                   // tiles with all 64 keys valid
+  stage(0, 0, BKV > S);
+  int t = 0;
+  for (; t + 1 < nfull; t += 2) {
+    tile(S0{}, std::false_type{}, t);
+    tile(S1{}, std::false_type{}, t + 1);
+  }
+  if (t < nfull) {
+    tile(S0{}, std::false_type{}, t);
+    ++t;
+    if (t < ntiles) tile(S1{}, std::true_type{}, t);
+  } else if (t < ntiles) {
+    tile(S0{}, std::true_type{}, t);
   }
 
   // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = 32dt + (r&3) + 8(r>>2) + 4hh
@@ -195,8 +258,13 @@ extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, voi
     return RT_E_ALIGN;
   if (ld < (int64_t)H * DH || ldo < (int64_t)H * DH) return RT_E_SHAPE;
   const dim3 grid((S + BQ - 1) / BQ, H, B);
-  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,
-                     scale * 1.4426950408889634f);
+  static int abl = -1;      // RT_ATT_ABLATE=1|2|3: timing-only builds (wrong results): 1 = no softmax math, 2 = no loads/barriers
+  if (abl < 0) { const char* e = getenv("RT_ATT_ABLATE"); abl = e ? atoi(e) : 0; }
+#define ATT_LAUNCH(A)                                                                                                   \
+  hipLaunchKernelGGL(attention_fwd_kernel<A>, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,        \
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,                \
+                     scale * 1.4426950408889634f)
+  if (abl == 1) ATT_LAUNCH(1); else if (abl == 2) ATT_LAUNCH(2); else if (abl == 3) ATT_LAUNCH(3); else ATT_LAUNCH(0);
+#undef ATT_LAUNCH
   return rt_hip_status();
 }
