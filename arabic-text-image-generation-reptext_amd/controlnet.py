@@ -111,7 +111,7 @@ class FluxControlNetModel(_MMDiTBase):
                 txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, return_dict: bool = True,
                 _rowscale: Optional[torch.Tensor] = None, _accumulate_into: Optional[Sequence[torch.Tensor]] = None,
-                _accumulate_single_into: Optional[Sequence[torch.Tensor]] = None):
+                _accumulate_single_into: Optional[Sequence[torch.Tensor]] = None, _mods: Optional["mmdit.StepMods"] = None):
         """Same contract as CN:216-413. ``joint_attention_kwargs`` is accepted and ignored (LoRA scale plumbing, no
         PEFT on this path). The private ``_rowscale`` / ``_accumulate_into`` arguments let the pipeline fuse its
         regional mask (PIPE:1062) and the sum over text lines (PIPE:1076-1080) into the zero-linear epilogues."""
@@ -138,7 +138,7 @@ class FluxControlNetModel(_MMDiTBase):
                             P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, x_t,
                               bias=self.context_embedder.bias.data)])
         ops.linear(cond.contiguous(), self.controlnet_x_embedder.weight.data, x_i, bias=self.controlnet_x_embedder.bias.data, res=x_i)
-        temb = self._temb(ws, timestep, guidance, pooled_projections)
+        temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
 
         scale = float(conditioning_scale)
@@ -155,11 +155,11 @@ class FluxControlNetModel(_MMDiTBase):
 
         block_samples: List[torch.Tensor] = []
         for i, pl in enumerate(doubles):
-            mmdit.run_double(pl, ws, temb, cos, sin, H)
+            mmdit.run_double(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.double[i])
             block_samples.append(head(self.controlnet_blocks[i], _accumulate_into, i))
         single_samples: List[torch.Tensor] = []
         for i, pl in enumerate(singles):
-            mmdit.run_single(pl, ws, temb, cos, sin, H)
+            mmdit.run_single(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.single[i])
             single_samples.append(head(self.controlnet_single_blocks[i], _accumulate_single_into, i))
 
         bs = block_samples if block_samples else None

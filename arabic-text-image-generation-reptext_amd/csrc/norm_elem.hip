@@ -302,6 +302,17 @@ __global__ void masked_accumulate_kernel(const bf16_t* __restrict__ x, bf16_t* _
   }
 }
 
+// hi = bf16(silu(x)), lo = bf16(silu(x) - hi): two-term bf16 split so a bf16 MFMA GEMM reproduces an fp32-activation product
+__global__ void silu_split_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n,
+                                  int apply_silu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = apply_silu ? silu_f(x[i]) : x[i];
+    const bf16_t h = f32_to_bf16(v);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+  }
+}
+
 inline int grid_for(int64_t n, int block) {
   int64_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -431,6 +442,13 @@ int rt_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
 int rt_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
   if (!x || !y || n < 1) return RT_E_BADARG;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+  return rt_hip_status();
+}
+
+int rt_silu_split_bf16(const float* x, void* hi, void* lo, int64_t n, int32_t apply_silu, void* stream) {
+  if (!x || !hi || !lo || n < 1) return RT_E_BADARG;
+  hipLaunchKernelGGL(silu_split_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n,
+                     apply_silu);
   return rt_hip_status();
 }
 

@@ -146,16 +146,78 @@ def time_text_embed(tte, ws: Workspace, t1000: torch.Tensor, g1000: Optional[tor
     return ws.temb
 
 
-def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None) -> None:
+class EmbedScratch:
+    """The two [B,d] fp32 buffers time_text_embed needs, without a full Workspace."""
+
+    def __init__(self, B: int, d: int, device):
+        self.B = B
+        self.temb = torch.empty(B, d, device=device, dtype=F32)
+        self.tmp = torch.empty(B, d, device=device, dtype=F32)
+
+
+@dataclass
+class StepMods:
+    """adaLN vectors of one denoising step, per block: fp32 row-slices of a ModulationTable."""
+
+    double: List[tuple]                  # (image [B,6d], text [B,6d])
+    single: List[torch.Tensor]           # [B,3d]
+    out: Optional[torch.Tensor]          # [B,2d] (norm_out), transformer only
+
+
+class ModulationTable:
+    """All adaLN projections `linear(silu(temb))` (A.1 step 1, A.2, A.3) of a model for EVERY step of a schedule at once.
+
+    temb depends only on (timestep, guidance, pooled text) — all known before the loop (PIPE:960-967,1025-1032) — so the
+    63 per-step weight-streaming GEMVs (6.4 GB of adaLN weights per step) become one M = steps·B GEMM per block, issued
+    once per image: the weights are streamed twice (hi + lo pass) instead of `steps` times. The two-term bf16 split of
+    silu(temb) keeps fp32-activation accuracy on the bf16 MFMA path."""
+
+    def __init__(self, temb_all: torch.Tensor, n_steps: int, B: int, doubles, singles, out_lin=None):
+        self.n, self.B = n_steps, B
+        hi, lo = ops.silu_split(temb_all, apply_silu=True)
+        dev = temb_all.device
+        M = temb_all.shape[0]
+
+        def out_buf(w):
+            return torch.empty(M, w.shape[0], device=dev, dtype=F32)
+
+        self.double, self.single, self.out = [], [], None
+        for pl in doubles:
+            oi, ot = out_buf(pl.ada_img_w), out_buf(pl.ada_txt_w)
+            ops.linear_grouped([P(hi, pl.ada_img_w, oi, bias=pl.ada_img_b), P(hi, pl.ada_txt_w, ot, bias=pl.ada_txt_b)])
+            ops.linear_grouped([P(lo, pl.ada_img_w, oi, res=oi), P(lo, pl.ada_txt_w, ot, res=ot)])
+            self.double.append((oi, ot))
+        for pl in singles:
+            o = out_buf(pl.ada_w)
+            ops.linear(hi, pl.ada_w, o, bias=pl.ada_b)
+            ops.linear(lo, pl.ada_w, o, res=o)
+            self.single.append(o)
+        if out_lin is not None:
+            o = out_buf(out_lin.weight.data)
+            ops.linear(hi, out_lin.weight.data, o, bias=out_lin.bias.data)
+            ops.linear(lo, out_lin.weight.data, o, res=o)
+            self.out = o
+
+    def step(self, i: int) -> StepMods:
+        r = slice(i * self.B, (i + 1) * self.B)
+        return StepMods([(a[r], b[r]) for a, b in self.double], [s[r] for s in self.single], None if self.out is None else self.out[r])
+
+
+def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None,
+               mods: Optional[tuple] = None) -> None:
     """One FluxTransformerBlock on ws.x in place (A.1). ``inject`` [B,N,d] bf16 is added to the image rows after the
-    block (A.3 ControlNet residual), fused into the last GEMM's epilogue."""
+    block (A.3 ControlNet residual), fused into the last GEMM's epilogue. ``mods`` = precomputed (image, text) adaLN
+    vectors for this step (ModulationTable); computed here from ``temb`` when absent."""
     T, d = ws.T, ws.d
     x_t, x_i = ws.x[:, :T], ws.x[:, T:]
     xn_t, xn_i = ws.xn[:, :T], ws.xn[:, T:]
-    mi, mt = ws.mod_a, ws.mod_b
     # 1. adaLN-Zero vectors: chunk order shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    ops.gemv(temb, pl.ada_img_w, pl.ada_img_b, mi, silu_in=True)
-    ops.gemv(temb, pl.ada_txt_w, pl.ada_txt_b, mt, silu_in=True)
+    if mods is not None:
+        mi, mt = mods
+    else:
+        mi, mt = ws.mod_a, ws.mod_b
+        ops.gemv(temb, pl.ada_img_w, pl.ada_img_b, mi, silu_in=True)
+        ops.gemv(temb, pl.ada_txt_w, pl.ada_txt_b, mt, silu_in=True)
     ch = lambda m, i: m[:, i * d : (i + 1) * d]
     # 2. norm + modulate
     ops.layernorm_modulate(x_i, xn_i, ch(mi, 0), ch(mi, 1))
@@ -178,11 +240,15 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
                         P(ws.ffh[:, :T], pl.ff2_txt_w, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t)])
 
 
-def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None) -> None:
+def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None,
+               mods: Optional[torch.Tensor] = None) -> None:
     """One FluxSingleTransformerBlock on ws.x in place (A.2)."""
     T, d = ws.T, ws.d
-    m = ws.mod_a[:, : 3 * d]
-    ops.gemv(temb, pl.ada_w, pl.ada_b, m, silu_in=True)                       # shift, scale, gate
+    if mods is not None:
+        m = mods
+    else:
+        m = ws.mod_a[:, : 3 * d]
+        ops.gemv(temb, pl.ada_w, pl.ada_b, m, silu_in=True)                   # shift, scale, gate
     ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
     big = ws.big
     ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)        # [k|v|q|gelu(mlp)]

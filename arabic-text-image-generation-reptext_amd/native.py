@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_unpack_latents": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "rt_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "rt_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
+    "rt_silu_split_bf16": [_vp, _vp, _vp, _i64, _i32, _vp],
     "rt_masked_accumulate": [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp],
 }
 # AutoencoderKL entries (csrc/vae.hip)

@@ -275,3 +275,12 @@ def masked_accumulate_(y: torch.Tensor, x: torch.Tensor, rowscale: Optional[torc
     native.check("rt_masked_accumulate", native.load().rt_masked_accumulate(
         _dev(x, "x", BF16), _dev(y, "y", BF16), _opt(rowscale, "rowscale", F32), float(alpha), B, R, D, int(accumulate), _stream()))
     return y
+
+
+def silu_split(x: torch.Tensor, apply_silu: bool = True):
+    """(hi, lo) bf16 with hi + lo ~= silu(x) to ~2^-17 relative: A operands for a two-pass bf16 GEMM on fp32 activations."""
+    x = x.contiguous()
+    hi = torch.empty(x.shape, device=x.device, dtype=BF16)
+    lo = torch.empty(x.shape, device=x.device, dtype=BF16)
+    native.check("rt_silu_split_bf16", native.load().rt_silu_split_bf16(_dev(x, "x", F32), hi.data_ptr(), lo.data_ptr(), x.numel(), int(apply_silu), _stream()))
+    return hi, lo

@@ -469,6 +469,11 @@ class FluxControlNetPipeline:
         guidance = torch.full((B,), float(guidance_scale), device=device, dtype=torch.float32) if self.transformer.config.guidance_embeds else None
         rowscales = [m.reshape(-1).to(torch.float32).contiguous() for m in masks]
         num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
+        # adaLN vectors of every block for every step, once per image (timesteps/guidance/pooled are loop-invariant inputs)
+        model_ts = [t / 1000.0 for t in tvals]
+        tab_t = self.transformer.build_modulation_table(model_ts, guidance, pooled)
+        fused_cn = isinstance(self.controlnet, FluxControlNetModel) and len(hints) > 0
+        tab_c = self.controlnet.build_modulation_table(model_ts[: max(0, min(len(model_ts), cn_steps))], guidance, pooled) if fused_cn and cn_steps > 0 else None
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(tvals):
                 if self.interrupt:
@@ -485,14 +490,16 @@ class FluxControlNetPipeline:
                             timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=prompt_embeds,
                             txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs,
                             return_dict=False, _rowscale=rs, _accumulate_into=merged if line > 0 else None,
-                            _accumulate_single_into=merged_single if line > 0 else None)
+                            _accumulate_single_into=merged_single if line > 0 else None,
+                            _mods=None if tab_c is None else tab_c.step(i))
                     if line == 0:
                         merged, merged_single = samples, single_samples
                     # line > 0: the zero-linear epilogues already summed into `merged` (PIPE:1076-1087)
                 noise_pred = self.transformer(
                     hidden_states=latents, timestep=timestep, guidance=guidance, pooled_projections=pooled,
                     encoder_hidden_states=prompt_embeds, controlnet_block_samples=merged, controlnet_single_block_samples=merged_single,
-                    txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False)[0]
+                    txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False,
+                    _mods=tab_t.step(i))[0]
                 latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
                 if callback is not None:
                     env = {"latents": latents, "prompt_embeds": prompt_embeds}

@@ -116,6 +116,19 @@ class _MMDiTBase(nn.Module, WeightsIO):
                 g1000 = g1000.expand(ws.B).contiguous()
         return mmdit.time_text_embed(self.time_text_embed, ws, t1000.contiguous(), g1000, pooled)
 
+    def build_modulation_table(self, timesteps, guidance, pooled) -> "mmdit.ModulationTable":
+        """adaLN vectors of every block for every entry of ``timesteps`` (model-scale values, i.e. t/1000 as the pipeline
+        passes them, PIPE:1048,1094) — see mmdit.ModulationTable. guidance [B] / pooled [B,P] as in ``forward``."""
+        doubles, singles = self._ensure_plans()
+        B, d = pooled.shape[0], self.inner_dim
+        dev = pooled.device
+        sc = mmdit.EmbedScratch(B, d, dev)
+        temb_all = torch.empty(len(timesteps) * B, d, device=dev, dtype=torch.float32)
+        for i, t in enumerate(timesteps):
+            ts = torch.full((B,), float(t), device=dev, dtype=torch.float32)
+            temb_all[i * B : (i + 1) * B].copy_(self._temb(sc, ts, guidance, pooled))
+        return mmdit.ModulationTable(temb_all, len(timesteps), B, doubles, singles, getattr(self, "norm_out", None) and self.norm_out.linear)
+
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype=None, subfolder: Optional[str] = None, device=None, **unused):
         d = cls._resolve_dir(path, subfolder)
@@ -148,7 +161,8 @@ class FluxTransformer2DModel(_MMDiTBase):
                 pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, img_ids: torch.Tensor = None,
                 txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
-                controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False):
+                controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False,
+                _mods: Optional["mmdit.StepMods"] = None):
         doubles, singles = self._ensure_plans()
         cfg = self.config
         B, N, _ = hidden_states.shape
@@ -164,7 +178,7 @@ class FluxTransformer2DModel(_MMDiTBase):
         ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, ws.x[:, T:], bias=self.x_embedder.bias.data),
                             P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, ws.x[:, :T],
                               bias=self.context_embedder.bias.data)])
-        temb = self._temb(ws, timestep, guidance, pooled_projections)
+        temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
         nl, ns = len(doubles), len(singles)
         for i, pl in enumerate(doubles):
@@ -172,15 +186,18 @@ class FluxTransformer2DModel(_MMDiTBase):
             if controlnet_block_samples is not None:
                 ns_c = len(controlnet_block_samples)
                 inj = controlnet_block_samples[i % ns_c] if controlnet_blocks_repeat else controlnet_block_samples[i // int(math.ceil(nl / ns_c))]
-            mmdit.run_double(pl, ws, temb, cos, sin, H, inject=inj)
+            mmdit.run_double(pl, ws, temb, cos, sin, H, inject=inj, mods=None if _mods is None else _mods.double[i])
         for i, pl in enumerate(singles):
             inj = None
             if controlnet_single_block_samples is not None:
                 inj = controlnet_single_block_samples[i // int(math.ceil(ns / len(controlnet_single_block_samples)))]
-            mmdit.run_single(pl, ws, temb, cos, sin, H, inject=inj)
+            mmdit.run_single(pl, ws, temb, cos, sin, H, inject=inj, mods=None if _mods is None else _mods.single[i])
         # AdaLayerNormContinuous: chunk order (scale, shift)  — A.3
-        m = ws.mod_a[:, : 2 * d]
-        ops.gemv(temb, self.norm_out.linear.weight.data, self.norm_out.linear.bias.data, m, silu_in=True)
+        if _mods is not None:
+            m = _mods.out
+        else:
+            m = ws.mod_a[:, : 2 * d]
+            ops.gemv(temb, self.norm_out.linear.weight.data, self.norm_out.linear.bias.data, m, silu_in=True)
         ops.layernorm_modulate(ws.x[:, T:], ws.xn[:, T:], m[:, d : 2 * d], m[:, :d])
         out = torch.empty(Bc, N, self.proj_out.weight.shape[0], device=hs.device, dtype=torch.bfloat16)
         ops.linear(ws.xn[:, T:], self.proj_out.weight.data, out, bias=self.proj_out.bias.data)
