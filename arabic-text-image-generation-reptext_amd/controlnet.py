@@ -137,7 +137,18 @@ class FluxControlNetModel(_MMDiTBase):
         ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, x_i, bias=self.x_embedder.bias.data),
                             P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, x_t,
                               bias=self.context_embedder.bias.data)])
-        ops.linear(cond.contiguous(), self.controlnet_x_embedder.weight.data, x_i, bias=self.controlnet_x_embedder.bias.data, res=x_i)
+        cxw = self.controlnet_x_embedder.weight.data
+        kin = cxw.shape[1]
+        if kin % 64:
+            # e.g. the inpaint tower's 64 + 4 = 68 hint channels (INP:807-813): the MFMA K-loop steps by 64, so pad K with zeros
+            kp = (kin + 63) // 64 * 64
+            if getattr(self, "_cx_pad", None) is None or self._cx_pad[1] != cxw.data_ptr():
+                wpad = torch.zeros(cxw.shape[0], kp, device=cxw.device, dtype=cxw.dtype)
+                wpad[:, :kin] = cxw
+                self._cx_pad = (wpad, cxw.data_ptr())
+            cxw = self._cx_pad[0]
+            cond = torch.nn.functional.pad(cond, (0, kp - kin))
+        ops.linear(cond.contiguous(), cxw, x_i, bias=self.controlnet_x_embedder.bias.data, res=x_i)
         temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
 

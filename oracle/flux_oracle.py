@@ -283,6 +283,59 @@ def denoise_loop(tp: Params, tcfg: dict, cp: Optional[Params], ccfg: Optional[di
     return latents
 
 
+def denoise_loop_inpaint(tp: Params, tcfg: dict, cp: Params, ccfg: dict, ip: Params, icfg: dict, latents, prompt_embeds, pooled,
+                         neg_prompt_embeds, neg_pooled, control_images, control_masks, inpaint_cond, sigmas, img_ids, txt_ids,
+                         guidance_scale: float, true_guidance_scale: float, conditioning_scale: float = 1.0,
+                         conditioning_scale_inpaint: float = 1.0, conditioning_step: int = 10 ** 9):
+    """Hot loop of the inpaint pipeline, pipeline_flux_controlnet_inpaint.py:1138-1285 (B = 1).
+
+    CFG is on when guidance_scale > 1 (INP:241-242): conditioning = cat([negative, positive]) (INP:1033-1035), latents stay
+    batch 1 and broadcast inside the models (Q6); the inpaint tower runs unmasked every step and its residuals are added only
+    when the text towers produced some (INP:1231-1245); step 0 uses zero velocity, later steps uncond + s·(text − uncond) with
+    s = true_guidance_scale (INP:1264-1270)."""
+    cfg_on = guidance_scale > 1
+    if cfg_on:
+        pe = torch.cat([neg_prompt_embeds, prompt_embeds], dim=0)
+        pl = torch.cat([neg_pooled, pooled], dim=0)
+        rep = lambda t: torch.cat([t, t], dim=0)
+    else:
+        pe, pl = prompt_embeds, pooled
+        rep = lambda t: t
+    hints = [rep(c) for c in control_images]
+    icond = rep(inpaint_cond)
+    n = len(sigmas) - 1
+    for i in range(n):
+        B = latents.shape[0]
+        timestep = sigmas[i].expand(B)
+        guidance = torch.full((B,), float(guidance_scale)) if tcfg.get("guidance_embeds", False) else None
+        lat_in = latents.expand(pe.shape[0], -1, -1) if cfg_on else latents        # what broadcasting inside the models amounts to
+        ts_in = timestep.expand(pe.shape[0]) if cfg_on else timestep
+        g_in = guidance.expand(pe.shape[0]) if (cfg_on and guidance is not None) else guidance
+        merged = None
+        for line, cond in enumerate(hints):
+            samples = None
+            if i < conditioning_step:
+                samples, _ = controlnet_forward(cp, ccfg, lat_in, cond, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in,
+                                                conditioning_scale=conditioning_scale)
+                mask = control_masks[line] if len(control_masks) > 0 else None
+                if mask is not None:
+                    samples = [mask * s for s in samples]
+            if line == 0:
+                merged = samples
+            elif samples is not None and merged is not None:
+                merged = [a + b for a, b in zip(merged, samples)]
+        isamples, _ = controlnet_forward(ip, icfg, lat_in, icond, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in,
+                                         conditioning_scale=conditioning_scale_inpaint)
+        if isamples is not None and merged is not None:
+            merged = [a + b for a, b in zip(merged, isamples)]
+        v = transformer_forward(tp, tcfg, lat_in, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in, controlnet_block_samples=merged)
+        if cfg_on:
+            v_u, v_t = v.chunk(2)
+            v = v_u + true_guidance_scale * (v_t - v_u) if i > 0 else v_t * 0.0
+        latents = euler_step(latents, v, float(sigmas[i]), float(sigmas[i + 1]))
+    return latents
+
+
 # --------------------------------------------------------------------------------------- synthetic weights
 def _lin(p: Params, name: str, out_f: int, in_f: int, gen: torch.Generator, std: float = 0.02, bias_std: float = 0.0):
     p[name + ".weight"] = torch.randn(out_f, in_f, generator=gen) * std

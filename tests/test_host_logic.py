@@ -167,3 +167,24 @@ def test_randn_tensor_device_rule():
     assert torch.equal(c[1:], torch.randn((1, 4), generator=torch.Generator().manual_seed(2)))
     with pytest.raises(ValueError):
         randn_tensor((3, 4), [torch.Generator()], "cpu", torch.float32)
+
+
+def test_inpaint_dropin_signature_and_mask_processor():
+    """infer_inpaint.py:4 import + the kwargs infer_inpaint.py:132-151 passes; INP:846-883 order and defaults."""
+    from pipeline_flux_controlnet_inpaint import FluxControlNetPipeline as Inpaint
+
+    names = list(inspect.signature(Inpaint.__call__).parameters)[1:]
+    assert names[:5] == ["prompt", "prompt_2", "true_guidance_scale", "negative_prompt", "negative_prompt_2"]
+    for k in ("control_image_inpaint", "control_mask_inpaint", "controlnet_conditioning_scale_inpaint", "control_glyph", "control_mask"):
+        assert k in names
+    d = {k: v.default for k, v in inspect.signature(Inpaint.__call__).parameters.items()}
+    assert d["true_guidance_scale"] == 3.5 and d["guidance_scale"] == 7.0 and d["num_inference_steps"] == 28
+    assert list(inspect.signature(Inpaint.__init__).parameters)[1:] == ["scheduler", "vae", "text_encoder", "tokenizer", "text_encoder_2",
+                                                                        "tokenizer_2", "transformer", "controlnet", "controlnet_inpaint"]
+    from reptext_amd.image_processor import VaeImageProcessor
+    from PIL import Image
+
+    mp = VaeImageProcessor(vae_scale_factor=16, do_normalize=False, do_binarize=True, do_convert_grayscale=True)       # INP:228-234
+    m = np.zeros((32, 32, 3), np.uint8); m[:16] = 200
+    x = mp.preprocess(Image.fromarray(m), height=32, width=32)
+    assert x.shape == (1, 1, 32, 32) and set(x.unique().tolist()) == {0.0, 1.0} and float(x[0, 0, 0, 0]) == 1.0

@@ -157,3 +157,51 @@ def test_pipeline_c1_latents_and_image(vae_pair, gpu):
     assert img.size == (256, 256)
     with pytest.raises(ValueError):
         pipe(prompt_embeds=pe.to(gpu), height=250, width=256)        # PIPE:496
+
+
+def test_inpaint_pipeline_cfg_and_second_tower(vae_pair, gpu):
+    """BASELINE config 4 shape family: text tower (masked) + inpaint tower (68 hint channels, unmasked) + true CFG with the
+    zero-velocity first step, against the oracle restatement of INP:1138-1285."""
+    from PIL import Image
+
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline_inpaint import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    INP_CN = dict(SMALL_T, num_layers=2, num_single_layers=0, extra_condition_channels=4)
+    tp = orc.init_mmdit_params(SMALL_T, seed=21)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=22, controlnet=True)
+    ip = orc.init_mmdit_params(INP_CN, seed=23, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    cni = FluxControlNetModel(**INP_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp); cni.load_state_dict(ip)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn, cni)
+    pipe.set_progress_bar_config(disable=True)
+    H = W = 256
+    N, T = 256, 64
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    pe, pooled, npe, npooled = r(1, T, 256), r(1, 64), r(1, T, 256), r(1, 64)
+    hint, hint_inp = r(1, N, 128), r(1, N, 68)
+    lat0 = orc.pack_latents(r(1, 16, 32, 32))
+    mask_np = np.zeros([H, W], dtype=np.uint8); mask_np[40:200, 30:120] = 255
+    rm = torch.nn.functional.interpolate(torch.from_numpy(mask_np)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1)
+    sig = orc.flow_sigmas(3, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    ids, tids = orc.latent_image_ids(32, 32), torch.zeros(T, 3)
+    ref = orc.denoise_loop_inpaint(tp, SMALL_T, cp, SMALL_CN, ip, INP_CN, lat0, pe, pooled, npe, npooled, [hint], [rm], hint_inp, sig, ids, tids,
+                                   guidance_scale=3.5, true_guidance_scale=2.0, conditioning_scale_inpaint=0.9)
+    b16 = lambda t: t.to(gpu, torch.bfloat16)
+    kw = dict(prompt_embeds=b16(pe), pooled_prompt_embeds=b16(pooled), negative_prompt_embeds=b16(npe), negative_pooled_prompt_embeds=b16(npooled),
+              height=H, width=W, num_inference_steps=3, guidance_scale=3.5, true_guidance_scale=2.0, control_image=[b16(hint)],
+              control_mask=[Image.fromarray(mask_np)], control_image_inpaint=b16(hint_inp), controlnet_conditioning_scale_inpaint=0.9,
+              latents=b16(lat0), output_type="latent")
+    out = pipe(**kw).images
+    err = rel_l2(out.float().cpu(), ref)
+    print(f"inpaint pipeline (CFG, 2 towers, 3 steps) latents rel-L2 {err:.3e}")
+    assert err < 2e-2
+    # step 0 is a zero-velocity step (Q7): a 1-step run returns the initial latents unchanged
+    one = pipe(**dict(kw, num_inference_steps=1)).images
+    assert torch.equal(one, b16(lat0))
