@@ -45,7 +45,7 @@ def _flatten(c: Conditioning, dtype) -> torch.Tensor:
 
 
 def broadcast_conditioning(c: Optional[Conditioning], spec: Sequence[Tuple[str, Tuple[int, ...]]], device, src: int = 0,
-                           dtype=torch.bfloat16, mask_dtype=torch.float32) -> Conditioning:
+                           dtype=torch.bfloat16, mask_dtype=torch.float32, staging_device=None) -> Conditioning:
     """ONE `dist.broadcast` of a flat fp32 buffer holding every conditioning tensor back to back.
 
     Non-source ranks pass ``c=None`` and the static ``spec`` (names + shapes) all ranks agree on. fp32 on the wire keeps
@@ -58,10 +58,11 @@ def broadcast_conditioning(c: Optional[Conditioning], spec: Sequence[Tuple[str, 
             raise ValueError("source rank must provide the conditioning")
         if [tuple(s) for _, s in c.spec()] != [tuple(s) for _, s in spec]:
             raise ValueError("conditioning does not match the agreed spec")
-        flat = _flatten(c, torch.float32).to(device)
+        flat = _flatten(c, torch.float32).to(staging_device or device)
     else:
-        flat = torch.empty(n, device=device, dtype=torch.float32)
-    dist.broadcast(flat, src=src)
+        flat = torch.empty(n, device=staging_device or device, dtype=torch.float32)
+    dist.broadcast(flat, src=src)            # RCCL over xGMI (staging_device=None) — or gloo via host memory in rehearsals/tests
+    flat = flat.to(device)
     out: Dict[str, torch.Tensor] = {}
     o = 0
     for name, shape in spec:

@@ -167,11 +167,18 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("RT_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on a box with fewer GPUs than ranks
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs: one process per GPU is required for RCCL")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import reptext_amd.ops as ops
     from reptext_amd import dist as rdist
@@ -212,7 +219,7 @@ def main():
         m = pipe._region_masks([mask_img] * args.text_lines, "cpu", torch.float32)
         cond = rdist.Conditioning(pe, pooled, hints, [t.reshape(-1) for t in m])
     if world > 1:
-        cond = rdist.broadcast_conditioning(cond, spec, dev)
+        cond = rdist.broadcast_conditioning(cond, spec, dev, staging_device=("cpu" if backend == "gloo" else None))
     else:
         cond = rdist.Conditioning(cond.prompt_embeds.to(dev, bf16), cond.pooled.to(dev, bf16), [h.to(dev, bf16) for h in cond.hints],
                                   [m.to(dev) for m in cond.masks])
@@ -242,7 +249,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=("cpu" if backend == "gloo" else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
