@@ -31,12 +31,10 @@ constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64 between rescales
 
 __device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-// single-instruction 3-input max (fmaxf on MFMA outputs otherwise gets a canonicalising v_max in front of it)
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// 3-input max. Plain fmaxf so the compiler inserts the MFMA->VALU wait states itself: an inline-asm v_max3 here read the
+// accumulators before the MFMA had retired them (run-to-run differences in the running max; csrc/Makefile builds this file
+// with -fno-honor-nans so no canonicalising v_max is emitted in front and the pair folds to one v_max3_f32).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 typedef const __attribute__((address_space(3))) char* lds_cptr;
 __device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
