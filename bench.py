@@ -110,6 +110,17 @@ class GemmTimer:
         return len(self.events), sum(self.flops), tot_ms * 1e-3
 
 
+def pmc_traffic_bytes(kernel_key: str):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_traffic_pmc.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE over this same command, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
+    Counters cannot be read from inside the timed process, so the value is the last profiled one; null when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+            return int(json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """Cores this process may actually run on: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
     logical CPUs but grants a 16-CPU share; running 256 threads there oversubscribes 16x)."""
@@ -264,7 +275,7 @@ def main():
         n_launch, fl, sec = gt.result()
         ach = fl / sec / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                    "traffic": None, "kernel": "gemm_bf16_kernel", "launches": n_launch,
+                    "traffic": pmc_traffic_bytes("gemm"), "kernel": "gemm_bf16_kernel", "launches": n_launch,
                     "avg_launch_us": round(sec / n_launch * 1e6, 2), "avg_gflop_per_launch": round(fl / n_launch / 1e9, 2),
                     "e2e_tflops_per_gpu": round(fl_img * Bl * args.steps / elapsed / 1e12, 1),
                     "e2e_frac": round(fl_img * Bl * args.steps / elapsed / 2.5e15, 4)}
@@ -274,7 +285,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "images/sec (whole node), FLUX.1-dev+RepText CN, 1024^2, 28 steps",
+            "metric": f"images/sec (whole node), FLUX.1-dev+RepText CN, {H}^2, {args.inference_steps} steps",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "sec_per_image": round(elapsed / (args.steps * Bl), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
