@@ -156,12 +156,13 @@ class FluxControlNetModel(_MMDiTBase):
 
         def head(lin, dst_list, i):
             """zero-linear i on the current image rows: (W·h+b)·scale [·mask] [+ running sum] (CN:384-396)."""
+            a = mmdit.image_rows_bf16(ws)
             if dst_list is not None:
                 out = dst_list[i]
-                ops.linear(x_i, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale, res=out)
+                ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale, res=out)
             else:
                 out = torch.empty(Bc, N, d, device=hs.device, dtype=torch.bfloat16)
-                ops.linear(x_i, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale)
+                ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale)
             return out
 
         block_samples: List[torch.Tensor] = []

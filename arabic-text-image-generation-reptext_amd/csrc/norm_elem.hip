@@ -279,6 +279,23 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __rest
     y[i] = bf16_to_f32(x[i]);
 }
 
+// fp32 destination variant (fp32 residual stream): y[b][r][:] (+)= alpha * rowscale[r] * x[b][r][:]
+__global__ void masked_accumulate_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y,
+                                             const float* __restrict__ rowscale, float alpha, int batch, int rows, int D8,
+                                             int accumulate) {
+  const int64_t n = (int64_t)batch * rows * D8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)((i / D8) % rows);
+    const float m = alpha * (rowscale ? rowscale[r] : 1.0f);
+    const u32x4 a = reinterpret_cast<const u32x4*>(x)[i];
+    f32x4 lo = f32x4{bf16lo(a[0]), bf16hi(a[0]), bf16lo(a[1]), bf16hi(a[1])} * m;
+    f32x4 hi = f32x4{bf16lo(a[2]), bf16hi(a[2]), bf16lo(a[3]), bf16hi(a[3])} * m;
+    f32x4* yp = reinterpret_cast<f32x4*>(y) + 2 * i;
+    if (accumulate) { lo += yp[0]; hi += yp[1]; }
+    yp[0] = lo; yp[1] = hi;
+  }
+}
+
 // y[b][r][:] (+)= alpha * rowscale[r] * x[b][r][:], 8 elements per lane
 __global__ void masked_accumulate_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                          const float* __restrict__ rowscale, float alpha, int batch, int rows, int D8,
@@ -453,11 +470,16 @@ int rt_silu_split_bf16(const float* x, void* hi, void* lo, int64_t n, int32_t ap
 }
 
 int rt_masked_accumulate(const void* x, void* y, const float* rowscale, float alpha, int32_t batch, int32_t rows,
-                         int32_t D, int32_t accumulate, void* stream) {
+                         int32_t D, int32_t accumulate, int32_t y_f32, void* stream) {
   if (!x || !y || batch < 1 || rows < 1 || D < 8) return RT_E_BADARG;
   if (D % 8) return RT_E_SHAPE;
   if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(y, 16)) return RT_E_ALIGN;
   const int64_t n = (int64_t)batch * rows * (D / 8);
+  if (y_f32) {
+    hipLaunchKernelGGL(masked_accumulate_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (float*)y, rowscale, alpha, batch, rows, D / 8, accumulate);
+    return rt_hip_status();
+  }
   hipLaunchKernelGGL(masked_accumulate_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (bf16_t*)y, rowscale, alpha, batch, rows, D / 8, accumulate);
   return rt_hip_status();

@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -63,7 +63,7 @@ SIGNATURES = {
     "rt_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "rt_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
     "rt_silu_split_bf16": [_vp, _vp, _vp, _i64, _i32, _vp],
-    "rt_masked_accumulate": [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp],
+    "rt_masked_accumulate": [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp],
 }
 # AutoencoderKL entries (csrc/vae.hip)
 SIGNATURES.update({

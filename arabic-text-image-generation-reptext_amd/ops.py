@@ -266,14 +266,15 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def masked_accumulate_(y: torch.Tensor, x: torch.Tensor, rowscale: Optional[torch.Tensor], alpha: float = 1.0, accumulate: bool = True) -> torch.Tensor:
-    """y[b,r,:] (+)= alpha*rowscale[r]*x[b,r,:]; contiguous bf16 [B,R,D]."""
-    if x.shape != y.shape or x.dim() != 3 or not x.is_contiguous() or not y.is_contiguous():
-        raise ValueError("masked_accumulate_: contiguous [B,R,D] tensors of equal shape")
+    """y[b,r,:] (+)= alpha*rowscale[r]*x[b,r,:]; contiguous [B,R,D]; x bf16, y bf16 or f32."""
+    if x.shape != y.shape or x.dim() != 3 or not x.is_contiguous() or not y.is_contiguous() or y.dtype not in (BF16, F32):
+        raise ValueError("masked_accumulate_: contiguous [B,R,D] tensors of equal shape (y bf16 or f32)")
     B, R, D = x.shape
     if rowscale is not None and (rowscale.numel() != R or not rowscale.is_contiguous()):
         raise ValueError("rowscale must be contiguous with R elements")
     native.check("rt_masked_accumulate", native.load().rt_masked_accumulate(
-        _dev(x, "x", BF16), _dev(y, "y", BF16), _opt(rowscale, "rowscale", F32), float(alpha), B, R, D, int(accumulate), _stream()))
+        _dev(x, "x", BF16), _dev(y, "y"), _opt(rowscale, "rowscale", F32), float(alpha), B, R, D, int(accumulate),
+        int(y.dtype == F32), _stream()))
     return y
 
 

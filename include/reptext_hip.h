@@ -136,9 +136,9 @@ int rt_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
 /* hi = bf16(f(x)), lo = bf16(f(x) - hi), f = SiLU or identity: lets the adaLN projections of ALL denoising steps run as one
  * M = steps GEMM on MFMA (hi pass + lo pass accumulate) with fp32-activation accuracy (A.1 step 1, hoisted out of PIPE:1017). */
 int rt_silu_split_bf16(const float* x, void* hi, void* lo, int64_t n, int32_t apply_silu, void* stream);
-/* y[b][r][:] (+)= alpha · rowscale[r] · x[b][r][:]  — PIPE:1060-1087 masked sum over text lines (bf16). */
+/* y[b][r][:] (+)= alpha · rowscale[r] · x[b][r][:]  — PIPE:1060-1087 masked sum over text lines; x bf16, y bf16 or f32 (y_f32). */
 int rt_masked_accumulate(const void* x, void* y, const float* rowscale, float alpha,
-                         int32_t batch, int32_t rows, int32_t D, int32_t accumulate, void* stream);
+                         int32_t batch, int32_t rows, int32_t D, int32_t accumulate, int32_t y_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * AutoencoderKL (PIPE:467,705,711 encode; PIPE:1139 decode; Appendix A.7).
