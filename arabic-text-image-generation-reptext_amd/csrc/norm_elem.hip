@@ -230,6 +230,16 @@ __global__ void euler_step_tail_kernel(bf16_t* x, const bf16_t* v, float ds, int
   if (i < n) x[i] = f32_to_bf16(bf16_to_f32(x[i]) + ds * bf16_to_f32(v[i]));
 }
 
+// fp32 master latents: x32 += ds * v (v bf16); also emits the bf16 copy the next step's x_embedder reads
+__global__ void euler_step_f32_kernel(float* __restrict__ x, const bf16_t* __restrict__ v, bf16_t* __restrict__ xb, float ds,
+                                      int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float r = x[i] + ds * bf16_to_f32(v[i]);
+    x[i] = r;
+    if (xb) xb[i] = f32_to_bf16(r);
+  }
+}
+
 __global__ void cfg_mix_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ t, bf16_t* __restrict__ o,
                                float s, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -424,6 +434,13 @@ int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream)
   if (n8 * 8 < n)
     hipLaunchKernelGGL(euler_step_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (bf16_t*)x, (const bf16_t*)v,
                        dsigma, n8 * 8, n);
+  return rt_hip_status();
+}
+
+int rt_euler_step_f32(float* x, const void* v, void* x_bf16, float dsigma, int64_t n, void* stream) {
+  if (!x || !v || n < 1) return RT_E_BADARG;
+  hipLaunchKernelGGL(euler_step_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)v,
+                     (bf16_t*)x_bf16, dsigma, n);
   return rt_hip_status();
 }
 

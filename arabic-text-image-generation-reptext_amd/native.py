@@ -57,6 +57,7 @@ SIGNATURES = {
     "rt_qk_rmsnorm_rope": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_euler_step": [_vp, _vp, _f32, _i64, _vp],
+    "rt_euler_step_f32": [_vp, _vp, _vp, _f32, _i64, _vp],
     "rt_cfg_mix": [_vp, _vp, _vp, _f32, _i64, _vp],
     "rt_pack_latents": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "rt_unpack_latents": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],

@@ -226,6 +226,17 @@ def euler_step_(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> torch.Tensor
     return x
 
 
+def euler_step_f32_(x32: torch.Tensor, v: torch.Tensor, dsigma: float, x_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x32 += dsigma*v on an fp32 master state; optionally refreshes its bf16 copy."""
+    if not (x32.is_contiguous() and v.is_contiguous()) or x32.shape != v.shape:
+        raise ValueError("euler_step_f32_: contiguous tensors of equal shape")
+    if x_bf16 is not None and (x_bf16.shape != x32.shape or not x_bf16.is_contiguous()):
+        raise ValueError("x_bf16 must match x32")
+    native.check("rt_euler_step_f32", native.load().rt_euler_step_f32(_dev(x32, "x32", F32), _dev(v, "v", BF16), _opt(x_bf16, "x_bf16", BF16),
+                                                                      float(dsigma), x32.numel(), _stream()))
+    return x32
+
+
 def cfg_mix(v_uncond: torch.Tensor, v_text: torch.Tensor, s: float) -> torch.Tensor:
     u, t = v_uncond.contiguous(), v_text.contiguous()
     out = torch.empty_like(t)

@@ -474,6 +474,10 @@ class FluxControlNetPipeline:
         tab_t = self.transformer.build_modulation_table(model_ts, guidance, pooled)
         fused_cn = isinstance(self.controlnet, FluxControlNetModel) and len(hints) > 0
         tab_c = self.controlnet.build_modulation_table(model_ts[: max(0, min(len(model_ts), cn_steps))], guidance, pooled) if fused_cn and cn_steps > 0 else None
+        # fp32 master copy of the latents between steps (the models read its bf16 copy): the scheduler computes in fp32 anyway
+        # (A.6); not rounding the STATE 28 times keeps the loop close to the fp32 reference path. Callbacks see the bf16 copy.
+        lat32 = latents.to(torch.float32).contiguous()
+        latents = latents.to(torch.bfloat16).contiguous().clone()
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(tvals):
                 if self.interrupt:
@@ -500,11 +504,13 @@ class FluxControlNetPipeline:
                     encoder_hidden_states=prompt_embeds, controlnet_block_samples=merged, controlnet_single_block_samples=merged_single,
                     txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False,
                     _mods=tab_t.step(i))[0]
-                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+                self.scheduler.step_master_(noise_pred, lat32, latents)
                 if callback is not None:
                     env = {"latents": latents, "prompt_embeds": prompt_embeds}
                     out = callback(self, i, timesteps[i], {k: env[k] for k in callback_inputs})
-                    latents = out.pop("latents", latents)
+                    if "latents" in out:
+                        latents = out.pop("latents").to(torch.bfloat16).contiguous()
+                        lat32 = latents.to(torch.float32)
                     prompt_embeds = out.pop("prompt_embeds", prompt_embeds)
                 if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
                     bar.update()

@@ -231,6 +231,10 @@ class FluxControlNetPipeline(_BasePipeline):
         n_cn = max(0, min(len(model_ts), cn_steps))
         tab_c = self.controlnet.build_modulation_table(model_ts[:n_cn], g_tab, pooled) if (hints and n_cn > 0) else None
         tab_i = self.controlnet_inpaint.build_modulation_table(model_ts[:n_cn], g_tab, pooled) if (hints and n_cn > 0) else None
+        # fp32 master copy of the latents between steps (the models read its bf16 copy): the scheduler computes in fp32 anyway
+        # (A.6); not rounding the STATE 28 times keeps the loop close to the fp32 reference path. Callbacks see the bf16 copy.
+        lat32 = latents.to(torch.float32).contiguous()
+        latents = latents.to(torch.bfloat16).contiguous().clone()
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(tvals):
                 if self.interrupt:
@@ -268,11 +272,13 @@ class FluxControlNetPipeline(_BasePipeline):
                         noise_pred = ops.cfg_mix(uncond, text, float(true_scale))
                     else:
                         noise_pred = torch.zeros_like(text)                                # first step: zero velocity (Q7)
-                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+                self.scheduler.step_master_(noise_pred, lat32, latents)
                 if callback is not None:
                     env = {"latents": latents, "prompt_embeds": pe}
                     out = callback(self, i, timesteps[i], {k: env[k] for k in callback_inputs})
-                    latents = out.pop("latents", latents)
+                    if "latents" in out:
+                        latents = out.pop("latents").to(torch.bfloat16).contiguous()
+                        lat32 = latents.to(torch.float32)
                     pe = out.pop("prompt_embeds", pe)
                 if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
                     bar.update()

@@ -83,6 +83,15 @@ class FlowMatchEulerDiscreteScheduler:
         idx = (self.timesteps.cpu() == t).nonzero()
         self._step_index = int(idx[1 if len(idx) > 1 else 0]) if len(idx) > 0 else 0
 
+    def step_master_(self, model_output: torch.Tensor, sample32: torch.Tensor, sample_bf16: Optional[torch.Tensor] = None) -> None:
+        """In-place Euler step on an fp32 master copy of the latents (used by this repo's pipelines between steps; ``step`` keeps
+        the diffusers contract of returning the model dtype). Advances the step index exactly like ``step``."""
+        if self._step_index is None:
+            self._step_index = self._begin_index if self._begin_index is not None else 0
+        i = self._step_index
+        ops.euler_step_f32_(sample32, model_output.contiguous(), float(self.sigmas[i + 1] - self.sigmas[i]), sample_bf16)
+        self._step_index = i + 1
+
     def step(self, model_output: torch.Tensor, timestep: Union[float, torch.Tensor], sample: torch.Tensor,
              return_dict: bool = True, **unused):
         if self._step_index is None:

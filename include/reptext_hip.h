@@ -121,6 +121,11 @@ int rt_attention_fwd(const void* q, const void* k, const void* v, void* o,
 /* FlowMatchEulerDiscreteScheduler.step (PIPE:1109; A.6): x = bf16(f32(x) + dsigma·f32(v)), in place. */
 int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream);
 
+/* Same step on an fp32 master copy of the latents (x32 += dsigma·v, v bf16), optionally writing the bf16 copy the next model
+ * call reads. diffusers computes the step in fp32 and rounds the STATE back to bf16 every step; keeping the state in fp32
+ * removes 28 accumulated roundings (the fp32 CPU reference path keeps fp32 throughout). */
+int rt_euler_step_f32(float* x, const void* v, void* x_bf16 /* nullable */, float dsigma, int64_t n, void* stream);
+
 /* True-CFG mix of the inpaint pipeline (INP:1264-1270): out = uncond + s·(text − uncond); bf16. */
 int rt_cfg_mix(const void* v_uncond, const void* v_text, void* out, float s, int64_t n, void* stream);
 

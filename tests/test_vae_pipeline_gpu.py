@@ -205,3 +205,35 @@ def test_inpaint_pipeline_cfg_and_second_tower(vae_pair, gpu):
     # step 0 is a zero-velocity step (Q7): a 1-step run returns the initial latents unchanged
     one = pipe(**dict(kw, num_inference_steps=1)).images
     assert torch.equal(one, b16(lat0))
+
+
+def test_pipeline_many_steps_error_growth(vae_pair, gpu):
+    """28 steps (the BASELINE step count) at the C1 resolution with reduced-depth weights: the latent error vs the fp32 oracle
+    must not grow with the step count (fp32 master latents + fp32 residual stream)."""
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tp = orc.init_mmdit_params(SMALL_T, seed=41)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=42, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    N, T, steps = 256, 64, 28
+    g = torch.Generator().manual_seed(6)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    pe, pooled, hint = r(1, T, 256), r(1, 64), r(1, N, 128)
+    lat0 = orc.pack_latents(r(1, 16, 32, 32))
+    sig = orc.flow_sigmas(steps, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    ref = orc.denoise_loop(tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, [hint], [], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5,
+                           conditioning_step=20)
+    b16 = lambda t: t.to(gpu, torch.bfloat16)
+    out = pipe(prompt_embeds=b16(pe), pooled_prompt_embeds=b16(pooled), height=256, width=256, num_inference_steps=steps, guidance_scale=3.5,
+               control_image=[b16(hint)], controlnet_conditioning_step=20, latents=b16(lat0), output_type="latent").images
+    err = rel_l2(out.float().cpu(), ref)
+    print(f"28-step pipeline latents rel-L2 {err:.3e}")
+    assert err < 2e-2
