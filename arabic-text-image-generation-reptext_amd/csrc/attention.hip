@@ -18,7 +18,6 @@
 // LDS-DMA writes lane-linear, so the XOR is applied to each lane's source address.
 #include "rt_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace {
 
@@ -41,7 +40,6 @@ __device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <int ABL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* O,
     int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, int S, int H, float scale_log2) {
@@ -126,10 +124,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr bool RAGGED = decltype(ragged_c)::value;     // only the last tile of a sequence with S % 64 != 0
     constexpr int SB = SLOT * 2 * TILE_B;
-    if (!(ABL & 2) || t == 0) {
-      __syncthreads();                         // tile t landed (vmcnt(0) + barrier); the other slot is free
-      if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * BKV, (t + 2) * BKV > S);
-    }
+    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); the other slot is free
+    if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * BKV, (t + 2) * BKV > S);
 
     // ---- Sᵀ = K·Qᵀ : two 32-key tiles
     f32x16 s_acc[2];
@@ -155,15 +151,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     }
 
     // ---- online softmax in the log2 domain; the row's other 32 keys live in lane ^ 32.
-    float mx = 0.f;
-    if (!(ABL & 1)) {
-    mx = max3f(s_acc[0][0], s_acc[1][0], s_acc[0][1]);
+    float mx = max3f(s_acc[0][0], s_acc[1][0], s_acc[0][1]);
     mx = max3f(mx, s_acc[1][1], s_acc[0][2]);
 #pragma unroll
     for (int r = 3; r < 16; ++r) mx = max3f(mx, s_acc[0][r], s_acc[1][r - 1]);
     mx = max3f(mx, s_acc[1][15], s_acc[1][14]);
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2;
-    }
     // Deferred rescale: O and l are only rescaled when some row's max grew by more than RESCALE_THR (log2 units) over
     // the max it is currently normalised with; otherwise P = exp2(s - m_run) <= 2^THR, harmless in fp32 accumulators
     // and (being a relative format) in the bf16 P operand. The decision precedes every use of this tile's P.
@@ -186,10 +179,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float p;
-          if (ABL & 1) p = s_acc[kt][8 * s2 + j];
-          else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt][8 * s2 + j], scale_log2, -m_run));
-          if (!(ABL & 1)) psum += p;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt][8 * s2 + j], scale_log2, -m_run));
+          psum += p;
           pf[kt][s2][j] = (__bf16)p;
         }
     l_run += psum;
@@ -256,13 +247,8 @@ extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, voi
     return RT_E_ALIGN;
   if (ld < (int64_t)H * DH || ldo < (int64_t)H * DH) return RT_E_SHAPE;
   const dim3 grid((S + BQ - 1) / BQ, H, B);
-  static int abl = -1;      // RT_ATT_ABLATE=1|2|3: timing-only builds (wrong results): 1 = no softmax math, 2 = no loads/barriers
-  if (abl < 0) { const char* e = getenv("RT_ATT_ABLATE"); abl = e ? atoi(e) : 0; }
-#define ATT_LAUNCH(A)                                                                                                   \
-  hipLaunchKernelGGL(attention_fwd_kernel<A>, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,        \
-                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,                \
-                     scale * 1.4426950408889634f)
-  if (abl == 1) ATT_LAUNCH(1); else if (abl == 2) ATT_LAUNCH(2); else if (abl == 3) ATT_LAUNCH(3); else ATT_LAUNCH(0);
-#undef ATT_LAUNCH
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,
+                     scale * 1.4426950408889634f);
   return rt_hip_status();
 }
