@@ -187,7 +187,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                     # forces communicator creation now, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:                        # RCCL unusable on this node: the path has ONE broadcast, gloo can carry it
+                print(f"[bench] RCCL init failed on rank {rank} ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -291,7 +301,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
-                       "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast"},
+                       "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.depth_scale != 1.0:

@@ -237,3 +237,67 @@ def test_pipeline_many_steps_error_growth(vae_pair, gpu):
     err = rel_l2(out.float().cpu(), ref)
     print(f"28-step pipeline latents rel-L2 {err:.3e}")
     assert err < 2e-2
+
+
+def test_call_with_pil_hints_matches_oracle_prelude(vae_pair, gpu):
+    """The infer.py-shaped call: PIL canny / position / mask / glyph images go through preprocess -> VAE encode (posterior
+    sampled from the GLOBAL RNG, quirk Q2) -> pack -> loop (PIPE:928-982). The global-RNG draws are replayed in the test
+    (same device, same order, same shapes) so the oracle sees identical hint latents."""
+    from PIL import Image, ImageDraw
+
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    p_vae, vae = vae_pair
+    tp = orc.init_mmdit_params(SMALL_T, seed=51)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=52, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    H = W = 256
+    # synthetic glyph hint in the style of infer.py:71-100 (PIL only; cv2 is not needed for a synthetic edge image)
+    glyph = Image.new("RGB", (W, H), (0, 0, 0))
+    ImageDraw.Draw(glyph).rectangle((60, 90, 190, 150), fill=(255, 255, 255))
+    edges = Image.new("RGB", (W, H), (255, 255, 255))
+    ImageDraw.Draw(edges).rectangle((60, 90, 190, 150), outline=(0, 0, 0))
+    pos_np = np.zeros([H, W], dtype=np.uint8); pos_np[90:150, 60:190] = 255
+    mask_np = np.zeros([H, W], dtype=np.uint8); mask_np[85:155, 55:195] = 255
+    position, mask = Image.fromarray(pos_np), Image.fromarray(mask_np)
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    N, T = 256, 64
+    pe, pooled = r(1, T, 256), r(1, 64)
+    gen = torch.Generator().manual_seed(42)                     # CPU generator: reproducible for any device (utils.randn_tensor)
+
+    torch.manual_seed(1234)
+    out = pipe(prompt_embeds=pe.to(gpu, torch.bfloat16), pooled_prompt_embeds=pooled.to(gpu, torch.bfloat16), height=H, width=W,
+               num_inference_steps=2, guidance_scale=3.5, control_image=[edges], control_position=[position], control_mask=[mask],
+               control_glyph=glyph, generator=gen, output_type="latent").images
+
+    # ---- oracle replay of the prelude
+    torch.manual_seed(1234)
+    n_img = torch.randn(1, 16, 32, 32, device=gpu, dtype=torch.bfloat16).float().cpu()      # latent_dist.sample() of the canny hint
+    n_pos = torch.randn(1, 16, 32, 32, device=gpu, dtype=torch.bfloat16).float().cpu()      # ... of the position hint
+    gen2 = torch.Generator().manual_seed(42)
+    _glyph_noise = torch.randn(1, 16, 32, 32, generator=gen2, dtype=torch.float32)           # Q1: glyph posterior draw, result unused
+    noise = torch.randn(1, 16, 32, 32, generator=gen2, dtype=torch.bfloat16).float()
+    to_t = lambda im: torch.from_numpy(np.asarray(im).astype(np.float32) / 255.0)
+    x_img = (to_t(edges).permute(2, 0, 1)[None] * 2 - 1).to(torch.bfloat16).float()
+    x_pos = (to_t(position)[None, None] * 2 - 1).repeat(1, 3, 1, 1).to(torch.bfloat16).float()
+    hint = []
+    for x, n in ((x_img, n_img), (x_pos, n_pos)):
+        mean, logvar = vorc.encode_moments(p_vae, VAE_SMALL, x)
+        z = vorc.sample_latents(mean, logvar, n)
+        hint.append(((z - 0.1159) * 0.3611).to(torch.bfloat16).float())
+    packed_hint = orc.pack_latents(torch.cat(hint, dim=1))
+    rm = torch.nn.functional.interpolate(torch.from_numpy(mask_np)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1)
+    sig = orc.flow_sigmas(2, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    ref = orc.denoise_loop(tp, SMALL_T, cp, SMALL_CN, orc.pack_latents(noise), pe, pooled, [packed_hint], [rm], sig, orc.latent_image_ids(32, 32),
+                           torch.zeros(T, 3), 3.5)
+    err = rel_l2(out.float().cpu(), ref)
+    print(f"PIL-hint call (VAE-encoded hints, Q1/Q2 RNG order) latents rel-L2 {err:.3e}")
+    assert err < 3e-2
