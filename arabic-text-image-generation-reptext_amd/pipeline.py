@@ -444,7 +444,10 @@ class FluxControlNetPipeline:
                                 callback_on_step_end, callback_on_step_end_tensor_inputs, num_inference_steps)
 
         if output_type == "latent":
-            image = latents
+            # The parity tap (PIPE:1132-1133). The loop's state is kept in fp32 (A.6: the scheduler steps in fp32), and that state
+            # is what is returned: rounding it to bf16 here would by itself cost 1.8e-3 rel-L2, twice the whole loop's error.
+            # `.to(torch.bfloat16)` gives the reference's bf16-run dtype.
+            image = self._master_latents
         else:
             h2 = 2 * (int(height) // self.vae_scale_factor)
             w2 = 2 * (int(width) // self.vae_scale_factor)
@@ -514,4 +517,5 @@ class FluxControlNetPipeline:
                     prompt_embeds = out.pop("prompt_embeds", prompt_embeds)
                 if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
                     bar.update()
+        self._master_latents = lat32          # fp32 state of the loop; `latents` is its bf16 copy
         return latents

@@ -8,6 +8,7 @@ Functional restatement, stock torch CPU ops, weights in a flat dict keyed like a
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -15,6 +16,27 @@ import torch
 import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
+
+# Storage-precision emulation (off by default = the fp32 oracle). Under `stored_as(torch.bfloat16)` every value the HIP
+# path keeps in HBM as bf16 between fused stages (GEMM A operands, q/k/v, attention probabilities and output, GELU
+# hidden, ControlNet samples, velocity) is rounded to bf16 at that point; everything else stays fp32, as on the GPU
+# (residual stream, statistics, adaLN vectors, master latents). It separates dtype noise from logic error: GPU vs this
+# mode must agree to accumulation-order noise, while GPU vs the plain fp32 oracle carries the bf16 rounding floor.
+_STORE: Optional[torch.dtype] = None
+
+
+def _s(x: torch.Tensor) -> torch.Tensor:
+    return x if _STORE is None else x.to(_STORE).to(torch.float32)
+
+
+@contextlib.contextmanager
+def stored_as(dtype: Optional[torch.dtype]):
+    global _STORE
+    prev, _STORE = _STORE, dtype
+    try:
+        yield
+    finally:
+        _STORE = prev
 
 
 # --------------------------------------------------------------------------------------- primitives
@@ -86,8 +108,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor
     B, S, H, Dh = q.shape
     qh, kh, vh = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(Dh)
-    o = torch.softmax(s, dim=-1) @ vh
-    return o.permute(0, 2, 1, 3).reshape(B, S, H * Dh)
+    if _STORE is None:
+        o = torch.softmax(s, dim=-1) @ vh
+    else:   # row sum from the unrounded numerators, numerators rounded as the second product's operand
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = (_s(e) @ vh) / e.sum(dim=-1, keepdim=True)
+    return _s(o.permute(0, 2, 1, 3).reshape(B, S, H * Dh))
 
 
 # --------------------------------------------------------------------------------------- blocks
@@ -98,11 +124,11 @@ def double_block(p: Params, pre: str, h, e, temb, rope, H: int = 24, Dh: int = 1
     cos, sin = rope
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = linear(p, f"{pre}.norm1.linear", silu(temb)).chunk(6, dim=-1)
     csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = linear(p, f"{pre}.norm1_context.linear", silu(temb)).chunk(6, dim=-1)
-    nh = layer_norm(h) * (1 + sc_a[:, None]) + sh_a[:, None]
-    ne = layer_norm(e) * (1 + csc_a[:, None]) + csh_a[:, None]
+    nh = _s(layer_norm(h) * (1 + sc_a[:, None]) + sh_a[:, None])
+    ne = _s(layer_norm(e) * (1 + csc_a[:, None]) + csh_a[:, None])
 
     def heads(x):
-        return x.reshape(x.shape[0], x.shape[1], H, Dh)
+        return _s(x).reshape(x.shape[0], x.shape[1], H, Dh)
 
     q = rms_norm(heads(linear(p, f"{pre}.attn.to_q", nh)), p[f"{pre}.attn.norm_q.weight"])
     k = rms_norm(heads(linear(p, f"{pre}.attn.to_k", nh)), p[f"{pre}.attn.norm_k.weight"])
@@ -110,20 +136,20 @@ def double_block(p: Params, pre: str, h, e, temb, rope, H: int = 24, Dh: int = 1
     eq = rms_norm(heads(linear(p, f"{pre}.attn.add_q_proj", ne)), p[f"{pre}.attn.norm_added_q.weight"])
     ek = rms_norm(heads(linear(p, f"{pre}.attn.add_k_proj", ne)), p[f"{pre}.attn.norm_added_k.weight"])
     ev = heads(linear(p, f"{pre}.attn.add_v_proj", ne))
-    Q = apply_rope(torch.cat([eq, q], dim=1), cos, sin)   # text first
-    K = apply_rope(torch.cat([ek, k], dim=1), cos, sin)
+    Q = _s(apply_rope(torch.cat([eq, q], dim=1), cos, sin))   # text first
+    K = _s(apply_rope(torch.cat([ek, k], dim=1), cos, sin))
     V = torch.cat([ev, v], dim=1)
     A = attention(Q, K, V)
     a_e = linear(p, f"{pre}.attn.to_add_out", A[:, :T])
     a_h = linear(p, f"{pre}.attn.to_out.0", A[:, T:])
 
     def ff(name, x):
-        return linear(p, f"{pre}.{name}.net.2", gelu_tanh(linear(p, f"{pre}.{name}.net.0.proj", x)))
+        return linear(p, f"{pre}.{name}.net.2", _s(gelu_tanh(linear(p, f"{pre}.{name}.net.0.proj", x))))
 
     h = h + g_a[:, None] * a_h
-    h = h + g_m[:, None] * ff("ff", layer_norm(h) * (1 + sc_m[:, None]) + sh_m[:, None])
+    h = h + g_m[:, None] * ff("ff", _s(layer_norm(h) * (1 + sc_m[:, None]) + sh_m[:, None]))
     e = e + cg_a[:, None] * a_e
-    e = e + cg_m[:, None] * ff("ff_context", layer_norm(e) * (1 + csc_m[:, None]) + csh_m[:, None])
+    e = e + cg_m[:, None] * ff("ff_context", _s(layer_norm(e) * (1 + csc_m[:, None]) + csh_m[:, None]))
     return e, h
 
 
@@ -132,25 +158,29 @@ def single_block(p: Params, pre: str, x, temb, rope, H: int = 24, Dh: int = 128)
     B, S, d = x.shape
     cos, sin = rope
     sh, sc, g = linear(p, f"{pre}.norm.linear", silu(temb)).chunk(3, dim=-1)
-    nx = layer_norm(x) * (1 + sc[:, None]) + sh[:, None]
-    m = gelu_tanh(linear(p, f"{pre}.proj_mlp", nx))
-    q = rms_norm(linear(p, f"{pre}.attn.to_q", nx).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_q.weight"])
-    k = rms_norm(linear(p, f"{pre}.attn.to_k", nx).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_k.weight"])
-    v = linear(p, f"{pre}.attn.to_v", nx).reshape(B, S, H, Dh)
-    A = attention(apply_rope(q, cos, sin), apply_rope(k, cos, sin), v)
+    nx = _s(layer_norm(x) * (1 + sc[:, None]) + sh[:, None])
+    m = _s(gelu_tanh(linear(p, f"{pre}.proj_mlp", nx)))
+    q = rms_norm(_s(linear(p, f"{pre}.attn.to_q", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_q.weight"])
+    k = rms_norm(_s(linear(p, f"{pre}.attn.to_k", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_k.weight"])
+    v = _s(linear(p, f"{pre}.attn.to_v", nx)).reshape(B, S, H, Dh)
+    A = attention(_s(apply_rope(q, cos, sin)), _s(apply_rope(k, cos, sin)), v)
     return x + g[:, None] * linear(p, f"{pre}.proj_out", torch.cat([A, m], dim=2))
 
 
 # --------------------------------------------------------------------------------------- models
 def controlnet_forward(p: Params, cfg: dict, hidden_states, controlnet_cond, encoder_hidden_states, pooled_projections,
-                       timestep, img_ids, txt_ids, guidance=None, conditioning_scale: float = 1.0):
-    """FluxControlNetModel.forward, CN:277-408 (union mode excluded: CN:294-301 is out of scope)."""
+                       timestep, img_ids, txt_ids, guidance=None, conditioning_scale: float = 1.0, _store_samples: bool = True):
+    """FluxControlNetModel.forward, CN:277-408 (union mode excluded: CN:294-301 is out of scope).
+
+    `_store_samples` only matters under stored_as(): the loops pass False and round after their mask/sum, where the HIP
+    path (which fuses both into the zero-linear epilogue) rounds."""
     H, Dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
-    h = linear(p, "x_embedder", hidden_states) + linear(p, "controlnet_x_embedder", controlnet_cond)      # CN:277-280
+    st = _s if _store_samples else (lambda t: t)
+    h = linear(p, "x_embedder", _s(hidden_states)) + linear(p, "controlnet_x_embedder", _s(controlnet_cond))  # CN:277-280
     t1000 = timestep.float() * 1000                                                                         # CN:282
     g1000 = guidance.float() * 1000 if (guidance is not None and cfg.get("guidance_embeds", False)) else None
     temb = time_text_embed(p, "time_text_embed", t1000, g1000, pooled_projections)                         # CN:287-291
-    e = linear(p, "context_embedder", encoder_hidden_states)                                                # CN:292
+    e = linear(p, "context_embedder", _s(encoder_hidden_states))                                            # CN:292
     rope = rope_table(torch.cat([txt_ids, img_ids], dim=0).float(), cfg.get("axes_dims_rope", (16, 56, 56)))  # CN:316-317
     block_samples = []
     for i in range(cfg["num_layers"]):                                                                       # CN:320-349
@@ -162,8 +192,8 @@ def controlnet_forward(p: Params, cfg: dict, hidden_states, controlnet_cond, enc
     for i in range(cfg["num_single_layers"]):                                                                # CN:354-381
         x = single_block(p, f"single_transformer_blocks.{i}", x, temb, rope, H, Dh)
         single_samples.append(x[:, T:])
-    outs = [linear(p, f"controlnet_blocks.{i}", s) * conditioning_scale for i, s in enumerate(block_samples)]   # CN:384-396
-    souts = [linear(p, f"controlnet_single_blocks.{i}", s) * conditioning_scale for i, s in enumerate(single_samples)]
+    outs = [st(linear(p, f"controlnet_blocks.{i}", _s(s)) * conditioning_scale) for i, s in enumerate(block_samples)]   # CN:384-396
+    souts = [st(linear(p, f"controlnet_single_blocks.{i}", _s(s)) * conditioning_scale) for i, s in enumerate(single_samples)]
     return (outs or None), (souts or None)                                                                   # CN:398-408
 
 
@@ -172,11 +202,11 @@ def transformer_forward(p: Params, cfg: dict, hidden_states, encoder_hidden_stat
                         controlnet_single_block_samples=None):
     """FluxTransformer2DModel.forward (A.3), call site PIPE:1092-1104."""
     H, Dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
-    h = linear(p, "x_embedder", hidden_states)
+    h = linear(p, "x_embedder", _s(hidden_states))
     t1000 = timestep.float() * 1000
     g1000 = guidance.float() * 1000 if (guidance is not None and cfg.get("guidance_embeds", False)) else None
     temb = time_text_embed(p, "time_text_embed", t1000, g1000, pooled_projections)
-    e = linear(p, "context_embedder", encoder_hidden_states)
+    e = linear(p, "context_embedder", _s(encoder_hidden_states))
     rope = rope_table(torch.cat([txt_ids, img_ids], dim=0).float(), cfg.get("axes_dims_rope", (16, 56, 56)))
     nl, ns = cfg["num_layers"], cfg["num_single_layers"]
     for i in range(nl):
@@ -193,8 +223,8 @@ def transformer_forward(p: Params, cfg: dict, hidden_states, encoder_hidden_stat
             x = torch.cat([x[:, :T], x[:, T:] + controlnet_single_block_samples[i // k]], dim=1)
     h = x[:, T:]
     scale, shift = linear(p, "norm_out.linear", silu(temb)).chunk(2, dim=-1)      # SCALE first (A.3)
-    h = layer_norm(h) * (1 + scale[:, None]) + shift[:, None]
-    return linear(p, "proj_out", h)
+    h = _s(layer_norm(h) * (1 + scale[:, None]) + shift[:, None])
+    return _s(linear(p, "proj_out", h))
 
 
 # --------------------------------------------------------------------------------------- scheduler / latents
@@ -264,7 +294,7 @@ def denoise_loop(tp: Params, tcfg: dict, cp: Optional[Params], ccfg: Optional[di
         for line, cond in enumerate(control_images):                         # PIPE:1037-1087
             if i < conditioning_step and cp is not None:
                 samples, _ = controlnet_forward(cp, ccfg, latents, cond, prompt_embeds, pooled, timestep, img_ids, txt_ids,
-                                                guidance=guidance, conditioning_scale=conditioning_scale)
+                                                guidance=guidance, conditioning_scale=conditioning_scale, _store_samples=False)
             else:
                 samples = None
             if samples is not None:
@@ -272,9 +302,9 @@ def denoise_loop(tp: Params, tcfg: dict, cp: Optional[Params], ccfg: Optional[di
                 if mask is not None:
                     samples = [mask * s for s in samples]
             if line == 0:
-                merged = samples
+                merged = None if samples is None else [_s(a) for a in samples]
             elif samples is not None and merged is not None:
-                merged = [a + b for a, b in zip(merged, samples)]
+                merged = [_s(a + b) for a, b in zip(merged, samples)]
         v = transformer_forward(tp, tcfg, latents, prompt_embeds, pooled, timestep, img_ids, txt_ids, guidance=guidance,
                                 controlnet_block_samples=merged)
         latents = euler_step(latents, v, float(sigmas[i]), float(sigmas[i + 1]))   # PIPE:1109
@@ -316,22 +346,22 @@ def denoise_loop_inpaint(tp: Params, tcfg: dict, cp: Params, ccfg: dict, ip: Par
             samples = None
             if i < conditioning_step:
                 samples, _ = controlnet_forward(cp, ccfg, lat_in, cond, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in,
-                                                conditioning_scale=conditioning_scale)
+                                                conditioning_scale=conditioning_scale, _store_samples=False)
                 mask = control_masks[line] if len(control_masks) > 0 else None
                 if mask is not None:
                     samples = [mask * s for s in samples]
             if line == 0:
-                merged = samples
+                merged = None if samples is None else [_s(a) for a in samples]
             elif samples is not None and merged is not None:
-                merged = [a + b for a, b in zip(merged, samples)]
+                merged = [_s(a + b) for a, b in zip(merged, samples)]
         isamples, _ = controlnet_forward(ip, icfg, lat_in, icond, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in,
-                                         conditioning_scale=conditioning_scale_inpaint)
+                                         conditioning_scale=conditioning_scale_inpaint, _store_samples=False)
         if isamples is not None and merged is not None:
-            merged = [a + b for a, b in zip(merged, isamples)]
+            merged = [_s(a + b) for a, b in zip(merged, isamples)]
         v = transformer_forward(tp, tcfg, lat_in, pe, pl, ts_in, img_ids, txt_ids, guidance=g_in, controlnet_block_samples=merged)
         if cfg_on:
             v_u, v_t = v.chunk(2)
-            v = v_u + true_guidance_scale * (v_t - v_u) if i > 0 else v_t * 0.0
+            v = _s(v_u + true_guidance_scale * (v_t - v_u)) if i > 0 else v_t * 0.0
         latents = euler_step(latents, v, float(sigmas[i]), float(sigmas[i + 1]))
     return latents
 

@@ -5,6 +5,14 @@ bf16-rounded on both sides, so the difference is compute precision only. The GPU
 bf16 between fused stages (as the reference's bf16 run does between EVERY op), the oracle is fp32 end to end.
 Tolerance: rel-L2 ≤ 2e-2 on model outputs — measured values are printed and recorded in DESIGN.md; the
 reference's own bf16-vs-fp32 discrepancy on the same graphs is of the same order (bf16 has 8 significand bits).
+
+Second comparator: the SAME oracle under `stored_as(bfloat16)`, which rounds exactly the values the HIP path keeps in
+HBM as bf16 — a CPU run at the GPU's storage precision. Its own distance from the fp32 oracle is the dtype floor for
+the graph under test. (Roundings amplify tiny accumulation-order differences back up to one bf16 ulp within a few
+stages — rms after a rounding is sqrt(delta*ulp) — so two bf16-storage runs never agree much below the floor either.)
+`assert_at_dtype_floor` therefore checks the self-calibrating statement: the GPU result is no further from the fp32
+oracle than the CPU-at-same-precision run is (+25 % slack), and closer to that run than the floor. A logic error adds
+to the first number; dtype noise cannot. This is the test that separates the two.
 """
 import pytest
 import torch
@@ -17,6 +25,12 @@ from oracle import flux_oracle as orc  # noqa: E402
 def rel_l2(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def assert_at_dtype_floor(err_fp32, err_stored, floor):
+    """err_fp32: GPU vs fp32 oracle; err_stored: GPU vs bf16-storage oracle; floor: bf16-storage oracle vs fp32 oracle."""
+    assert err_fp32 <= 1.25 * floor + 1e-4, (err_fp32, floor)
+    assert err_stored <= floor + 1e-4, (err_stored, floor)
 
 
 SMALL_T = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=4,
@@ -64,8 +78,13 @@ def test_transformer_forward(models, gpu, B):
     out = tr(hidden_states=d["latents"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["timestep"],
              img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0]
     err = rel_l2(out.float().cpu(), ref)
-    print(f"transformer B={B} rel-L2 {err:.3e}")
+    with orc.stored_as(torch.bfloat16):
+        ref16 = orc.transformer_forward(tp, SMALL_T, x["latents"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"], x["txt_ids"],
+                                        guidance=x["guidance"])
+    err16 = rel_l2(out.float().cpu(), ref16)
+    print(f"transformer B={B} rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle (oracle-vs-oracle {rel_l2(ref16, ref):.3e})")
     assert err < 2e-2
+    assert_at_dtype_floor(err, err16, rel_l2(ref16, ref))
 
 
 def test_controlnet_forward_and_injection(models, gpu):
@@ -79,10 +98,14 @@ def test_controlnet_forward_and_injection(models, gpu):
               pooled_projections=d["pooled"], timestep=d["timestep"], img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"])
     bs, ss = cn(**kw, return_dict=False)
     assert len(bs) == 2 and len(ss) == 1
-    for a, b in zip(bs + ss, rb + rs):
-        err = rel_l2(a.float().cpu(), b)
-        print(f"controlnet sample rel-L2 {err:.3e}")
+    with orc.stored_as(torch.bfloat16):
+        rb16, rs16 = orc.controlnet_forward(cp, SMALL_CN, x["latents"], x["cond"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"],
+                                            x["txt_ids"], guidance=x["guidance"], conditioning_scale=0.8)
+    for a, b, b16 in zip(bs + ss, rb + rs, rb16 + rs16):
+        err, err16 = rel_l2(a.float().cpu(), b), rel_l2(a.float().cpu(), b16)
+        print(f"controlnet sample rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle")
         assert err < 2e-2
+        assert_at_dtype_floor(err, err16, rel_l2(b16, b))
     out_obj = cn(**kw)                                   # return_dict=True form (CN:410-413)
     assert torch.equal(out_obj.controlnet_block_samples[0], bs[0])
     # fused mask + running sum == mask*sample + previous (PIPE:1062,1076-1080)
@@ -98,8 +121,13 @@ def test_controlnet_forward_and_injection(models, gpu):
              img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], controlnet_block_samples=bs,
              controlnet_single_block_samples=ss, return_dict=False)[0]
     err = rel_l2(out.float().cpu(), ref)
-    print(f"transformer+residuals rel-L2 {err:.3e}")
+    with orc.stored_as(torch.bfloat16):
+        ref16 = orc.transformer_forward(tp, SMALL_T, x["latents"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"], x["txt_ids"],
+                                        guidance=x["guidance"], controlnet_block_samples=rb16, controlnet_single_block_samples=rs16)
+    err16 = rel_l2(out.float().cpu(), ref16)
+    print(f"transformer+residuals rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle")
     assert err < 2e-2
+    assert_at_dtype_floor(err, err16, rel_l2(ref16, ref))
 
 
 def test_zero_init_controlnet_is_identity(models, gpu):

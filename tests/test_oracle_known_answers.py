@@ -125,3 +125,24 @@ def test_vae_oracle_shapes():
     assert img.shape == (1, 3, 32, 32)
     mean, logvar = vorc.encode_moments(p, cfg, torch.rand(1, 3, 32, 32) * 2 - 1)
     assert mean.shape == (1, 16, 4, 4) and float(logvar.max()) <= 20.0
+
+
+def test_storage_precision_mode_is_the_bf16_floor():
+    """`stored_as(bfloat16)` (the oracle at the HIP path's storage precision) must be off by default, deterministic, and sit
+    one bf16 rounding floor away from the fp32 oracle — the figure the GPU-vs-fp32-oracle errors in DESIGN.md §4 reproduce."""
+    cfg = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=4,
+               joint_attention_dim=256, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    tp = orc.init_mmdit_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    B, T, h2, w2 = 1, 64, 16, 24
+    N = (h2 // 2) * (w2 // 2)
+    args = (tp, cfg, r(B, N, 64), r(B, T, 256), r(B, 64), torch.full((B,), 0.622459), orc.latent_image_ids(h2, w2), torch.zeros(T, 3))
+    a = orc.transformer_forward(*args, guidance=torch.full((B,), 3.5))
+    with orc.stored_as(torch.bfloat16):
+        b = orc.transformer_forward(*args, guidance=torch.full((B,), 3.5))
+        b2 = orc.transformer_forward(*args, guidance=torch.full((B,), 3.5))
+    a2 = orc.transformer_forward(*args, guidance=torch.full((B,), 3.5))
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+    floor = float((a - b).norm() / a.norm())
+    assert 5e-4 < floor < 6e-3, floor

@@ -10,6 +10,9 @@ from oracle import flux_oracle as orc  # noqa: E402
 from oracle import vae_oracle as vorc  # noqa: E402
 
 
+from test_models_gpu import assert_at_dtype_floor  # noqa: E402  (GPU error must sit at the bf16-storage oracle's own floor)
+
+
 def rel_l2(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -141,8 +144,13 @@ def test_pipeline_c1_latents_and_image(vae_pair, gpu):
                controlnet_conditioning_scale=1.0, controlnet_conditioning_step=30, latents=lat0.to(gpu, torch.bfloat16),
                output_type="latent").images
     err = rel_l2(out.float().cpu(), ref)
-    print(f"C1-shape pipeline latents rel-L2 {err:.3e}")
-    assert err < 2e-2
+    with orc.stored_as(torch.bfloat16):     # same oracle, bf16 where the HIP path stores bf16: logic error without dtype noise
+        ref16 = orc.denoise_loop(tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, [hint], [rm], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
+    err16 = rel_l2(out.float().cpu(), ref16)
+    print(f"C1-shape pipeline latents rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle")
+    assert out.dtype == torch.float32          # the latent tap returns the loop's fp32 state
+    assert err < 1e-3                          # north-star tolerance (BASELINE.json): latents within 1e-3 rel-L2 of the CPU path
+    assert_at_dtype_floor(err, err16, rel_l2(ref16, ref))
     # zero-initialised tower == plain FLUX through the whole pipeline
     cn.zero_init_controlnet_()
     ref0 = orc.denoise_loop(tp, SMALL_T, None, None, lat0, pe, pooled, [], [], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
@@ -200,11 +208,16 @@ def test_inpaint_pipeline_cfg_and_second_tower(vae_pair, gpu):
               latents=b16(lat0), output_type="latent")
     out = pipe(**kw).images
     err = rel_l2(out.float().cpu(), ref)
-    print(f"inpaint pipeline (CFG, 2 towers, 3 steps) latents rel-L2 {err:.3e}")
-    assert err < 2e-2
+    with orc.stored_as(torch.bfloat16):
+        ref16 = orc.denoise_loop_inpaint(tp, SMALL_T, cp, SMALL_CN, ip, INP_CN, lat0, pe, pooled, npe, npooled, [hint], [rm], hint_inp, sig, ids,
+                                         tids, guidance_scale=3.5, true_guidance_scale=2.0, conditioning_scale_inpaint=0.9)
+    err16 = rel_l2(out.float().cpu(), ref16)
+    print(f"inpaint pipeline (CFG, 2 towers, 3 steps) latents rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle")
+    assert err < 5e-3                          # CFG extrapolation (scale 2) doubles the velocity error; floor check below
+    assert_at_dtype_floor(err, err16, rel_l2(ref16, ref))
     # step 0 is a zero-velocity step (Q7): a 1-step run returns the initial latents unchanged
     one = pipe(**dict(kw, num_inference_steps=1)).images
-    assert torch.equal(one, b16(lat0))
+    assert torch.equal(one, b16(lat0).float())
 
 
 def test_pipeline_many_steps_error_growth(vae_pair, gpu):
@@ -235,8 +248,13 @@ def test_pipeline_many_steps_error_growth(vae_pair, gpu):
     out = pipe(prompt_embeds=b16(pe), pooled_prompt_embeds=b16(pooled), height=256, width=256, num_inference_steps=steps, guidance_scale=3.5,
                control_image=[b16(hint)], controlnet_conditioning_step=20, latents=b16(lat0), output_type="latent").images
     err = rel_l2(out.float().cpu(), ref)
-    print(f"28-step pipeline latents rel-L2 {err:.3e}")
-    assert err < 2e-2
+    with orc.stored_as(torch.bfloat16):
+        ref16 = orc.denoise_loop(tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, [hint], [], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3),
+                                 3.5, conditioning_step=20)
+    err16 = rel_l2(out.float().cpu(), ref16)
+    print(f"28-step pipeline latents rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle")
+    assert err < 1e-3                          # north-star tolerance; measured 2.5e-4
+    assert_at_dtype_floor(err, err16, rel_l2(ref16, ref))
 
 
 def test_call_with_pil_hints_matches_oracle_prelude(vae_pair, gpu):
