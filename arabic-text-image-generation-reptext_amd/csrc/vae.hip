@@ -154,18 +154,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm over haloed NHWC. Pass 1: per-(b,group) sum / sum of squares (fp32 per thread, fp64 atomics).
-// Pass 2: normalise, affine, optional SiLU, write the interior of a haloed buffer.
+// GroupNorm over haloed NHWC, bitwise reproducible (no atomics: every sum has a fixed order).
+// Pass 1: per-thread fp32 partials per channel -> per-workgroup per-(group,stat) fp64 partial, summed in thread order.
+// Pass 2: per-(b,group,stat) sum of the workgroup partials in workgroup order. Pass 3: normalise, affine, optional SiLU,
+// write the interior of a haloed buffer.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats, int B,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ part, int B,
                                                         int H, int W, int C, int G, int pix_per_block) {
   // thread t handles channel chunk (t % (C/8)) of pixels t / (C/8) + k*(256/(C/8))
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);            // [G][2]
+  __shared__ float lane_part[256][17];                     // [thread][8 sums | 8 sums of squares], +1 pad
   const int c8 = C / 8;
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
   const int cpg = C / G;                                  // channels per group
   const int p0 = blockIdx.x * pix_per_block;
   const int pend = min(p0 + pix_per_block, H * W);
@@ -184,21 +183,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       se[2 * i + 1] += a1; qe[2 * i + 1] += a1 * a1;
     }
   }
-  // fold the 8 element partials into their groups (any channels-per-group), then one LDS atomic per group touched
-  float gs = 0.f, gq = 0.f;
-  int gcur = (chunk * 8) / cpg;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int gi = (chunk * 8 + i) / cpg;
-    if (gi != gcur) {
-      atomicAdd(&red[2 * gcur], gs); atomicAdd(&red[2 * gcur + 1], gq);
-      gs = 0.f; gq = 0.f; gcur = gi;
-    }
-    gs += se[i]; gq += qe[i];
-  }
-  atomicAdd(&red[2 * gcur], gs); atomicAdd(&red[2 * gcur + 1], gq);
+  for (int i = 0; i < 8; ++i) { lane_part[threadIdx.x][i] = se[i]; lane_part[threadIdx.x][8 + i] = qe[i]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(int64_t)b * 2 * G + i], (double)red[i]);
+  // thread j < 2G owns (group j/2, stat j%2): channels [g*cpg, (g+1)*cpg) over all pixel slots, in a fixed order
+  for (int j = threadIdx.x; j < 2 * G; j += blockDim.x) {
+    const int g = j >> 1, stat = j & 1;
+    double acc = 0.0;
+    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
+      const int ck = ch >> 3, el = (ch & 7) + 8 * stat;
+      for (int k = 0; k < pstep; ++k) acc += (double)lane_part[ck + k * c8][el];
+    }
+    part[((int64_t)b * gridDim.x + blockIdx.x) * 2 * G + j] = acc;
+  }
+}
+
+__global__ void gn_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk, int G2) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) acc += part[((int64_t)b * nblk + k) * G2 + j];
+    stats[(int64_t)b * G2 + j] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
@@ -403,21 +409,36 @@ int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* r
   return rt_hip_status();
 }
 
+static inline int gn_pix_per_block(int HW) {   // at most 1024 workgroups per image
+  int ppb = 1024;
+  while ((HW + ppb - 1) / ppb > 1024) ppb *= 2;
+  return ppb;
+}
+
+int64_t rt_groupnorm_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t G) {
+  if (B < 1 || H < 1 || W < 1 || G < 1) return 0;
+  const int HW = H * W;
+  const int ppb = gn_pix_per_block(HW);
+  const int64_t nblk = (HW + ppb - 1) / ppb;
+  return (int64_t)B * 2 * G * (nblk + 1) * (int64_t)sizeof(double);
+}
+
 int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, void* stats_ws, int32_t B,
                            int32_t H, int32_t W, int32_t C, int32_t G, float eps, int32_t silu, void* stream) {
   if (!x || !y || !gamma || !beta || !stats_ws || B < 1 || H < 1 || W < 1 || C < 8 || G < 1) return RT_E_BADARG;
   if (C % 8 || C % G || 256 % (C / 8) || C / 8 > 256) return RT_E_SHAPE;
-  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(y, 16) || !RT_ALIGNED(gamma, 16) || !RT_ALIGNED(beta, 16)) return RT_E_ALIGN;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(y, 16) || !RT_ALIGNED(gamma, 16) || !RT_ALIGNED(beta, 16) || !RT_ALIGNED(stats_ws, 8)) return RT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(stats_ws, 0, (size_t)B * G * 2 * sizeof(double), st);
-  if (e != hipSuccess) return (int)e;
   const int HW = H * W;
-  const int ppb = 1024;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), (size_t)2 * G * sizeof(float), st,
-                     (const bf16_t*)x, (double*)stats_ws, B, H, W, C, G, ppb);
+  const int ppb = gn_pix_per_block(HW);
+  const int nblk = (HW + ppb - 1) / ppb;
+  double* stats = (double*)stats_ws;                       // [B][2G] final sums
+  double* part = stats + (int64_t)B * 2 * G;               // [B][nblk][2G] workgroup partials
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, (const bf16_t*)x, part, B, H, W, C, G, ppb);
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(64), 0, st, (const double*)part, stats, nblk, 2 * G);
   const int64_t total = (int64_t)B * HW * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
-                     (const double*)stats_ws, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, eps, silu);
+                     (const double*)stats, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, eps, silu);
   return rt_hip_status();
 }
 

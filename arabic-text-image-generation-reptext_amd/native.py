@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -68,6 +68,7 @@ SIGNATURES = {
 }
 # AutoencoderKL entries (csrc/vae.hip)
 SIGNATURES.update({
+    "rt_groupnorm_ws_bytes": [_i32, _i32, _i32, _i32],
     "rt_groupnorm_silu_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "rt_conv2d_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_softmax_rows": [_vp, _vp, _i32, _i32, _f32, _vp],
@@ -77,6 +78,9 @@ SIGNATURES.update({
     "rt_haloed_nhwc_to_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_unpack_latents_haloed": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
 })
+
+# entries that do not return a status code
+RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64}
 
 _lib = None
 
@@ -101,7 +105,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     if lib.rt_abi_version() != ABI_VERSION:
         raise NativeLibraryMissing(f"{LIB_NAME} ABI {lib.rt_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib

@@ -217,7 +217,7 @@ class AutoencoderKL(nn.Module, WeightsIO):
             raise RuntimeError(f"AutoencoderKL is on {self.device}; move it to the GPU. There is no CPU fallback.")
         if self._pool is None:
             self._pool = _Pool(self.device)
-            self._stats = torch.zeros(64 * 64 * 2, device=self.device, dtype=torch.float64)
+            self._stats = None
 
     def _w(self, conv: _Conv) -> Tuple[torch.Tensor, torch.Tensor]:
         """[Cout,Cin,k,k] -> bf16 [Cout_pad4][k][k][Cin_pad64] (zero padded), cached per parameter."""
@@ -256,7 +256,11 @@ class AutoencoderKL(nn.Module, WeightsIO):
         B, Hp, Wp, C = x.shape
         if out is None:
             out = self._pool.get(B, Hp - 2, Wp - 2, C)
-        native.check("rt_groupnorm_silu_nhwc", native.load().rt_groupnorm_silu_nhwc(
+        lib = native.load()
+        need = int(lib.rt_groupnorm_ws_bytes(B, Hp - 2, Wp - 2, self.config.norm_num_groups))
+        if self._stats is None or self._stats.numel() * 8 < need:
+            self._stats = torch.empty((need + 7) // 8, device=self.device, dtype=torch.float64)
+        native.check("rt_groupnorm_silu_nhwc", lib.rt_groupnorm_silu_nhwc(
             x.data_ptr(), out.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), self._stats.data_ptr(), B, Hp - 2, Wp - 2, C,
             self.config.norm_num_groups, 1e-6, int(silu), _stream()))
         return out

@@ -151,7 +151,9 @@ int rt_masked_accumulate(const void* x, void* y, const float* rowscale, float al
  * written by these kernels, so 3x3 gathers need no bounds checks.
  * ---------------------------------------------------------------------------------------- */
 /* GroupNorm(G groups, eps, affine gamma/beta bf16 [C]) + optional SiLU over the interior of x -> interior of y.
- * stats_ws: device scratch of B*G*2 doubles (zeroed inside). C % 8 == 0, C % G == 0, 256 % (C/8) == 0. */
+ * stats_ws: device scratch of rt_groupnorm_ws_bytes(B,H,W,G) bytes (8-byte aligned; need not be zeroed). All sums run in a
+ * fixed order (no atomics): results are bitwise reproducible. C % 8 == 0, C % G == 0, 256 % (C/8) == 0. */
+int64_t rt_groupnorm_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t G);
 int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, void* stats_ws,
                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t G, float eps, int32_t silu, void* stream);
 /* 3x3 / 1x1 convolution as implicit GEMM on MFMA. x haloed [B][Hs+2][Ws+2][Cin], w bf16 [Cout][k][k][Cin] (repacked

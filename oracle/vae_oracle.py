@@ -11,6 +11,8 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+from .flux_oracle import _s   # identity unless flux_oracle.stored_as(dtype) is active (the HIP path's storage precision)
+
 Params = Dict[str, torch.Tensor]
 
 FLUX_VAE_CFG = dict(in_channels=3, out_channels=3, latent_channels=16, block_out_channels=(128, 256, 512, 512),
@@ -26,23 +28,23 @@ def _conv(p, name, x, stride=1, padding=1):
 
 
 def resnet(p: Params, pre: str, x, groups):
-    h = _conv(p, f"{pre}.conv1", F.silu(_gn(p, f"{pre}.norm1", x, groups)))
-    h = _conv(p, f"{pre}.conv2", F.silu(_gn(p, f"{pre}.norm2", h, groups)))
+    h = _s(_conv(p, f"{pre}.conv1", _s(F.silu(_gn(p, f"{pre}.norm1", x, groups)))))
+    h = _conv(p, f"{pre}.conv2", _s(F.silu(_gn(p, f"{pre}.norm2", h, groups))))
     if f"{pre}.conv_shortcut.weight" in p:
-        x = _conv(p, f"{pre}.conv_shortcut", x, padding=0)
-    return x + h
+        x = _s(_conv(p, f"{pre}.conv_shortcut", x, padding=0))
+    return _s(x + h)        # the HIP conv adds the skip in its epilogue: one rounding of the sum
 
 
 def mid_attention(p: Params, pre: str, x, groups):
     """Attention(512, heads=1, GroupNorm, residual_connection=True) of the mid block."""
     B, C, H, W = x.shape
-    t = _gn(p, f"{pre}.group_norm", x, groups).reshape(B, C, H * W).transpose(1, 2)
-    q = F.linear(t, p[f"{pre}.to_q.weight"], p[f"{pre}.to_q.bias"])
-    k = F.linear(t, p[f"{pre}.to_k.weight"], p[f"{pre}.to_k.bias"])
-    v = F.linear(t, p[f"{pre}.to_v.weight"], p[f"{pre}.to_v.bias"])
-    a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), dim=-1) @ v
+    t = _s(_gn(p, f"{pre}.group_norm", x, groups)).reshape(B, C, H * W).transpose(1, 2)
+    q = _s(F.linear(t, p[f"{pre}.to_q.weight"], p[f"{pre}.to_q.bias"]))
+    k = _s(F.linear(t, p[f"{pre}.to_k.weight"], p[f"{pre}.to_k.bias"]))
+    v = _s(F.linear(t, p[f"{pre}.to_v.weight"], p[f"{pre}.to_v.bias"]))
+    a = _s(_s(torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), dim=-1)) @ v)
     o = F.linear(a, p[f"{pre}.to_out.0.weight"], p[f"{pre}.to_out.0.bias"])
-    return x + o.transpose(1, 2).reshape(B, C, H, W)
+    return _s(x + o.transpose(1, 2).reshape(B, C, H, W))
 
 
 def _mid(p, pre, h, g):
@@ -55,15 +57,15 @@ def decode(p: Params, cfg: dict, z: torch.Tensor) -> torch.Tensor:
     """AutoencoderKL.decode (no post_quant_conv): z [B,16,h,w] (already /scaling + shift) -> [B,3,8h,8w]."""
     g = cfg["norm_num_groups"]
     chans = list(reversed(cfg["block_out_channels"]))
-    h = _conv(p, "decoder.conv_in", z)
+    h = _s(_conv(p, "decoder.conv_in", _s(z)))
     h = _mid(p, "decoder.mid_block", h, g)
     for i, _ in enumerate(chans):
         for j in range(cfg["layers_per_block"] + 1):
             h = resnet(p, f"decoder.up_blocks.{i}.resnets.{j}", h, g)
         if i < len(chans) - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = _conv(p, f"decoder.up_blocks.{i}.upsamplers.0.conv", h)
-    h = F.silu(_gn(p, "decoder.conv_norm_out", h, g))
+            h = _s(_conv(p, f"decoder.up_blocks.{i}.upsamplers.0.conv", h))
+    h = _s(F.silu(_gn(p, "decoder.conv_norm_out", h, g)))
     return _conv(p, "decoder.conv_out", h)
 
 
@@ -71,15 +73,15 @@ def encode_moments(p: Params, cfg: dict, x: torch.Tensor):
     """AutoencoderKL.encode -> (mean, logvar clamped to [-30, 20]); x [B,3,H,W] in [-1,1]."""
     g = cfg["norm_num_groups"]
     chans = list(cfg["block_out_channels"])
-    h = _conv(p, "encoder.conv_in", x)
+    h = _s(_conv(p, "encoder.conv_in", _s(x)))
     for i, _ in enumerate(chans):
         for j in range(cfg["layers_per_block"]):
             h = resnet(p, f"encoder.down_blocks.{i}.resnets.{j}", h, g)
         if i < len(chans) - 1:
             h = F.pad(h, (0, 1, 0, 1))
-            h = _conv(p, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=0)
+            h = _s(_conv(p, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=0))
     h = _mid(p, "encoder.mid_block", h, g)
-    h = _conv(p, "encoder.conv_out", F.silu(_gn(p, "encoder.conv_norm_out", h, g)))
+    h = _s(_conv(p, "encoder.conv_out", _s(F.silu(_gn(p, "encoder.conv_norm_out", h, g)))))
     mean, logvar = h.chunk(2, dim=1)
     return mean, logvar.clamp(-30.0, 20.0)
 

@@ -11,7 +11,7 @@ HBM as bf16 — a CPU run at the GPU's storage precision. Its own distance from 
 the graph under test. (Roundings amplify tiny accumulation-order differences back up to one bf16 ulp within a few
 stages — rms after a rounding is sqrt(delta*ulp) — so two bf16-storage runs never agree much below the floor either.)
 `assert_at_dtype_floor` therefore checks the self-calibrating statement: the GPU result is no further from the fp32
-oracle than the CPU-at-same-precision run is (+25 % slack), and closer to that run than the floor. A logic error adds
+oracle than the CPU-at-same-precision run is (+25 % slack), and within sqrt(2)·floor of that run (independent noise). A logic error adds
 to the first number; dtype noise cannot. This is the test that separates the two.
 """
 import pytest
@@ -30,7 +30,8 @@ def rel_l2(a, b):
 def assert_at_dtype_floor(err_fp32, err_stored, floor):
     """err_fp32: GPU vs fp32 oracle; err_stored: GPU vs bf16-storage oracle; floor: bf16-storage oracle vs fp32 oracle."""
     assert err_fp32 <= 1.25 * floor + 1e-4, (err_fp32, floor)
-    assert err_stored <= floor + 1e-4, (err_stored, floor)
+    # two runs at the same storage precision decorrelate over long chains; fully independent rounding noise gives sqrt(2)*floor
+    assert err_stored <= 1.45 * floor + 1e-4, (err_stored, floor)
 
 
 SMALL_T = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=4,
