@@ -249,12 +249,13 @@ def main():
     hints = [h.expand(Bl, -1, -1).contiguous() for h in cond.hints]
 
     lo, hi = rdist.shard_range(world * Bl, rank, world)
+    marks = []                                   # per timed pass: (start, loop end, decode end) events
 
     def one_pass(pass_idx):
         ids = [pass_idx * world * Bl + s for s in range(lo, hi)]
         noise = rdist.sample_noise(ids, (16, 2 * (H // 16), 2 * (W // 16)), 42, bf16, dev)
         lat = pipe._pack_latents(noise, Bl, 16, 2 * (H // 16), 2 * (W // 16))
-        return run_image(pipe, lat, pe, pooled, hints, cond.masks, H, W, args.inference_steps)
+        return run_image(pipe, lat, pe, pooled, hints, cond.masks, H, W, args.inference_steps, marks if pass_idx >= 0 else None)
 
     def barrier():
         if world > 1:
@@ -274,6 +275,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    timed_marks = marks[: args.steps]
+    loop_ms = sorted(e[0].elapsed_time(e[1]) for e in timed_marks)[len(timed_marks) // 2] if timed_marks else None
+    dec_ms = sorted(e[1].elapsed_time(e[2]) for e in timed_marks)[len(timed_marks) // 2] if timed_marks else None
     images = world * Bl * args.steps
     value = images / elapsed
     fl_img = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c)
@@ -298,6 +302,8 @@ def main():
             "metric": f"images/sec (whole node), FLUX.1-dev+RepText CN, {H}^2, {args.inference_steps} steps",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "sec_per_image": round(elapsed / (args.steps * Bl), 4),
+            "loop_only_ms_per_step": None if loop_ms is None else round(loop_ms, 2),          # rank 0, median over the timed passes
+            "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
@@ -311,8 +317,9 @@ def main():
         dist.destroy_process_group()
 
 
-def run_image(pipe, latents, pe, pooled, hints, rowscales, H, W, steps):
-    """The timed region: set up the schedule (host scalars), run the loop, decode to uint8."""
+def run_image(pipe, latents, pe, pooled, hints, rowscales, H, W, steps, marks=None):
+    """The timed region: set up the schedule (host scalars), run the loop, decode to uint8.
+    ``marks``: list receiving (start, loop_end, decode_end) events on the launch stream (loop-only / decode split)."""
     import numpy as np
     from reptext_amd.pipeline import retrieve_timesteps
     from reptext_amd.scheduler import calculate_shift
@@ -327,8 +334,17 @@ def run_image(pipe, latents, pe, pooled, hints, rowscales, H, W, steps):
     image_ids = pipe._prepare_latent_image_ids(B, h2, w2, dev, latents.dtype)
     pipe._guidance_scale, pipe._joint_attention_kwargs, pipe._interrupt = 3.5, None, False
     masks = [m.reshape(1, -1, 1) for m in rowscales]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
+    if ev:
+        ev[0].record()
     lat = pipe._denoise(latents, pe, pooled, text_ids, image_ids, timesteps, hints, masks, 3.5, 1.0, steps, None, None, [], n)
-    return pipe.vae.decode_packed(lat, h2, w2, output_u8=True)
+    if ev:
+        ev[1].record()
+    out = pipe.vae.decode_packed(lat, h2, w2, output_u8=True)
+    if ev:
+        ev[2].record()
+        marks.append(ev)
+    return out
 
 
 if __name__ == "__main__":
