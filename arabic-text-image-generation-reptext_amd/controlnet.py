@@ -111,10 +111,14 @@ class FluxControlNetModel(_MMDiTBase):
                 txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, return_dict: bool = True,
                 _rowscale: Optional[torch.Tensor] = None, _accumulate_into: Optional[Sequence[torch.Tensor]] = None,
-                _accumulate_single_into: Optional[Sequence[torch.Tensor]] = None, _mods: Optional["mmdit.StepMods"] = None):
+                _accumulate_single_into: Optional[Sequence[torch.Tensor]] = None, _mods: Optional["mmdit.StepMods"] = None,
+                _overwrite: bool = False, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None, _ws_tag: str = ""):
         """Same contract as CN:216-413. ``joint_attention_kwargs`` is accepted and ignored (LoRA scale plumbing, no
         PEFT on this path). The private ``_rowscale`` / ``_accumulate_into`` arguments let the pipeline fuse its
-        regional mask (PIPE:1062) and the sum over text lines (PIPE:1076-1080) into the zero-linear epilogues."""
+        regional mask (PIPE:1062) and the sum over text lines (PIPE:1076-1080) into the zero-linear epilogues; with
+        ``_overwrite`` the ``_accumulate_into`` buffers are written, not added to (first text line into preallocated
+        buffers). ``_sample_events[i]`` is recorded on the current stream once double-block sample i is complete and
+        ``_ws_tag`` selects a private workspace — both for running the tower on a side stream next to the transformer."""
         doubles, singles = self._ensure_plans()
         cfg = self.config
         if self.union:
@@ -125,7 +129,7 @@ class FluxControlNetModel(_MMDiTBase):
         B, N, _ = hidden_states.shape
         Bc, T, _ = encoder_hidden_states.shape
         H, d = cfg.num_attention_heads, self.inner_dim
-        ws = mmdit.workspace(Bc, T, N, d, hidden_states.device, need_single=len(singles) > 0)
+        ws = mmdit.workspace(Bc, T, N, d, hidden_states.device, need_single=len(singles) > 0, tag=_ws_tag)
         hs = hidden_states.to(torch.bfloat16)
         cond = controlnet_cond.to(torch.bfloat16)
         if hs.shape[0] != Bc:          # Q6: latents batch B against conditioning batch 2B broadcasts (B == 1 under CFG)
@@ -159,7 +163,7 @@ class FluxControlNetModel(_MMDiTBase):
             a = mmdit.image_rows_bf16(ws)
             if dst_list is not None:
                 out = dst_list[i]
-                ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale, res=out)
+                ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale, res=None if _overwrite else out)
             else:
                 out = torch.empty(Bc, N, d, device=hs.device, dtype=torch.bfloat16)
                 ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale)
@@ -169,6 +173,8 @@ class FluxControlNetModel(_MMDiTBase):
         for i, pl in enumerate(doubles):
             mmdit.run_double(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.double[i])
             block_samples.append(head(self.controlnet_blocks[i], _accumulate_into, i))
+            if _sample_events is not None:
+                _sample_events[i].record(torch.cuda.current_stream())
         single_samples: List[torch.Tensor] = []
         for i, pl in enumerate(singles):
             mmdit.run_single(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.single[i])

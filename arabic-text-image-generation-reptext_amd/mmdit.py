@@ -127,11 +127,12 @@ class Workspace:
 _WS_CACHE = {}
 
 
-def workspace(B, T, N, d, device, need_single) -> Workspace:
-    key = (B, T, N, d, str(device), RESIDUAL_F32)
+def workspace(B, T, N, d, device, need_single, tag: str = "") -> Workspace:
+    """``tag`` separates the buffers of models that may run concurrently on two streams (pipeline: tower vs transformer)."""
+    key = (B, T, N, d, str(device), RESIDUAL_F32, tag)
     ws = _WS_CACHE.get(key)
     if ws is None or (need_single and ws.big is None):
-        if len(_WS_CACHE) > 4:
+        if len(_WS_CACHE) > 6:
             _WS_CACHE.clear()
         ws = Workspace(B, T, N, d, device, need_single)
         _WS_CACHE[key] = ws

@@ -93,6 +93,13 @@ class _Progress:
             self.bar.update(n)
 
 
+# RT_OVERLAP_TOWER=1 runs the ControlNet tower on a side stream next to the transformer (see _denoise). Bitwise neutral and
+# measured at -1 % per image on MI355X (2.119 / 2.138 s vs 2.150 / 2.154 s): the idle CUs of a 27/32-full round are too few
+# for the tower's 256x256 tiles to use well. Off by default, which also keeps every kernel alone on the chip for the
+# per-kernel timings of bench.py's roofline pass and the rocprof summaries.
+OVERLAP_TOWER = os.environ.get("RT_OVERLAP_TOWER", "0") == "1"
+
+
 class FluxControlNetPipeline:
     model_cpu_offload_seq = "text_encoder->text_encoder_2->transformer->vae"
     _optional_components: List[str] = []
@@ -481,13 +488,43 @@ class FluxControlNetPipeline:
         # (A.6); not rounding the STATE 28 times keeps the loop close to the fp32 reference path. Callbacks see the bf16 copy.
         lat32 = latents.to(torch.float32).contiguous()
         latents = latents.to(torch.bfloat16).contiguous().clone()
+        # Tower ∥ transformer: within a step the tower's chain of kernels and the transformer's are independent except that
+        # transformer block i consumes tower sample i // 4 (A.3). The tower therefore runs on a side stream into preallocated
+        # sample buffers and the transformer waits, block by block, on the event of the sample it needs. At batch 1 most
+        # launches fill only 27/32 of their last round of workgroups (216 GEMM tiles on 256 CUs, 864 attention workgroups on
+        # 512 slots); two independent chains in flight fill some of those holes. Results are bitwise those of the serial order.
+        # Opt-in (OVERLAP_TOWER): the measured gain is 1 %.
+        overlap = (OVERLAP_TOWER and fused_cn and tab_c is not None and device.type == "cuda"
+                   and len(self.controlnet.single_transformer_blocks) == 0)
+        if overlap:
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
+                self._side_stream = torch.cuda.Stream(device=device)
+            side = self._side_stream
+            n_s = len(self.controlnet.transformer_blocks)
+            Bc, N_, d_ = prompt_embeds.shape[0], latents.shape[1], self.controlnet.inner_dim
+            sample_buf = [torch.empty(Bc, N_, d_, device=device, dtype=torch.bfloat16) for _ in range(n_s)]
+            sample_ev = [torch.cuda.Event() for _ in range(n_s)]
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(tvals):
                 if self.interrupt:
                     continue
                 timestep = torch.full((B,), t / 1000.0, device=device, dtype=torch.float32)      # PIPE:1025,1048 (Q4)
                 merged = merged_single = None
-                for line, hint in enumerate(hints):
+                events = None
+                if overlap and i < cn_steps:
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)                       # latents of this step (and, at i = 0, tables and hints) are ready
+                    with torch.cuda.stream(side):
+                        for line, hint in enumerate(hints):
+                            self.controlnet(
+                                hidden_states=latents, controlnet_cond=hint, controlnet_mode=control_mode, conditioning_scale=cn_scale,
+                                timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=prompt_embeds,
+                                txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs,
+                                return_dict=False, _rowscale=rowscales[line] if rowscales else None, _accumulate_into=sample_buf,
+                                _overwrite=(line == 0), _sample_events=sample_ev if line == len(hints) - 1 else None,
+                                _mods=tab_c.step(i), _ws_tag="tower")
+                    merged, events = sample_buf, sample_ev
+                for line, hint in enumerate(hints if events is None else ()):
                     if i >= cn_steps:                                                             # Q3
                         samples = single_samples = None
                     else:
@@ -506,7 +543,9 @@ class FluxControlNetPipeline:
                     hidden_states=latents, timestep=timestep, guidance=guidance, pooled_projections=pooled,
                     encoder_hidden_states=prompt_embeds, controlnet_block_samples=merged, controlnet_single_block_samples=merged_single,
                     txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False,
-                    _mods=tab_t.step(i))[0]
+                    _mods=tab_t.step(i), _sample_events=events)[0]
+                if events is not None:
+                    torch.cuda.current_stream().wait_stream(side)     # the tower has finished reading `latents` (its last sample is unused, Q5)
                 self.scheduler.step_master_(noise_pred, lat32, latents)
                 if callback is not None:
                     env = {"latents": latents, "prompt_embeds": prompt_embeds}

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional
+from typing import Sequence, Any, Dict, List, Optional
 
 import torch
 import torch.nn as nn
@@ -162,7 +162,9 @@ class FluxTransformer2DModel(_MMDiTBase):
                 txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
                 controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False,
-                _mods: Optional["mmdit.StepMods"] = None):
+                _mods: Optional["mmdit.StepMods"] = None, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None):
+        """``_sample_events[k]`` (optional): event another stream records when controlnet_block_samples[k] is complete; the
+        current stream waits for it right before the first block that consumes that sample."""
         doubles, singles = self._ensure_plans()
         cfg = self.config
         B, N, _ = hidden_states.shape
@@ -181,11 +183,16 @@ class FluxTransformer2DModel(_MMDiTBase):
         temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
         nl, ns = len(doubles), len(singles)
+        waited = set()
         for i, pl in enumerate(doubles):
             inj = None
             if controlnet_block_samples is not None:
                 ns_c = len(controlnet_block_samples)
-                inj = controlnet_block_samples[i % ns_c] if controlnet_blocks_repeat else controlnet_block_samples[i // int(math.ceil(nl / ns_c))]
+                k = i % ns_c if controlnet_blocks_repeat else i // int(math.ceil(nl / ns_c))
+                inj = controlnet_block_samples[k]
+                if _sample_events is not None and k not in waited:
+                    torch.cuda.current_stream().wait_event(_sample_events[k])
+                    waited.add(k)
             mmdit.run_double(pl, ws, temb, cos, sin, H, inject=inj, mods=None if _mods is None else _mods.double[i])
         for i, pl in enumerate(singles):
             inj = None

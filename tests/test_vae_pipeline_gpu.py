@@ -341,3 +341,35 @@ def test_vae_is_bitwise_reproducible(vae_pair, gpu):
     for _ in range(3):
         assert torch.equal(vae.decode(z, return_dict=False)[0], d0)
         assert torch.equal(vae.encode(x).latent_dist.mean, e0)
+
+
+def test_tower_stream_overlap_is_bitwise_neutral(vae_pair, gpu, monkeypatch):
+    """The ControlNet tower runs on a side stream next to the transformer (events per sample). Two text lines with masks,
+    tower active for 2 of 3 steps: latents must equal, bit for bit, those of the serial single-stream order."""
+    import reptext_amd.pipeline as P
+    from PIL import Image
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16).random_init_(61)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16).random_init_(62)
+    pipe = P.FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=g).to(gpu, torch.bfloat16)
+    pe, pooled = r(1, 64, 256), r(1, 64)
+    hints = [r(1, 256, 128), r(1, 256, 128)]
+    lat0 = r(1, 256, 64)
+    masks = []
+    for box in ((40, 120, 30, 200), (140, 220, 60, 240)):
+        m = np.zeros([256, 256], dtype=np.uint8); m[box[0]:box[1], box[2]:box[3]] = 255
+        masks.append(Image.fromarray(m))
+    kw = dict(prompt_embeds=pe, pooled_prompt_embeds=pooled, height=256, width=256, num_inference_steps=3, guidance_scale=3.5,
+              control_image=hints, control_mask=masks, controlnet_conditioning_step=2, latents=lat0, output_type="latent")
+    monkeypatch.setattr(P, "OVERLAP_TOWER", False)
+    serial = pipe(**kw).images.clone()
+    monkeypatch.setattr(P, "OVERLAP_TOWER", True)
+    for _ in range(3):
+        assert torch.equal(pipe(**kw).images, serial)
