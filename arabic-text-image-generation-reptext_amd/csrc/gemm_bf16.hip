@@ -41,11 +41,19 @@ struct Launch {
 // Epilogue for one wave: 8x4 accumulator fragments -> C. Lane owns rows mrow + 16i (i<8) and, per fragment column j,
 // the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the 4 fragment columns;
 // per-row terms (residual, add2) are fetched one row ahead of the row being finished, so no store waits on a load.
-template <bool OUT_F32>
+template <bool OUT_F32, bool FP8 = false>
 __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[8][4]) {
   const int rpb = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   bool nok[4];
   f32x4 bias4[4], gate4[4];
+  f32x4 wsc4[4];                                        // fp8 only: de-quantisation scale of the 4 output channels
+  if constexpr (FP8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol + 16 * j;
+      wsc4[j] = g.w_scale ? *reinterpret_cast<const f32x4*>(g.w_scale + (n < g.N ? n : 0)) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = ncol + 16 * j;
@@ -94,7 +102,9 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = ncol + 16 * j;
-      f32x4 v = acc[i][j] + bias4[j];
+      f32x4 v;
+      if constexpr (FP8) v = acc[i][j] * (wsc4[j] * (g.a_scale ? g.a_scale[(int64_t)bidx * g.M + mc] : 1.f)) + bias4[j];
+      else v = acc[i][j] + bias4[j];
       if (n >= g.gelu_from) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
@@ -253,7 +263,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_simple_kernel(const Laun
   } while (0)
 #define RT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// FP8 = false: bf16 operands, two v_mfma_f32_16x16x32_bf16 k-steps per 64-element K-tile.
+// FP8 = true : e4m3 operands, ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 128-element K-tile (block scales 1.0). A tile row is
+//              128 bytes either way, so staging, LDS image, swizzle, fragment addresses and the barrier schedule are shared.
+//              The MFMA's lane group j (lane>>4) is given the two 16-byte chunks j and j+4 of the row as its 32 k-values —
+//              the chunks the bf16 form reads for its k-steps 0 and 1 — for both operands alike, so the contraction still
+//              covers every k exactly once and the reads keep their conflict-free pattern.
+template <bool FP8>
+__global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
+  constexpr int ESZ = FP8 ? 1 : 2;                   // bytes per operand element
+  constexpr int BKE = 128 / ESZ;                     // elements per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
   LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -296,9 +318,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
   // ---- staging: part 0 = a0, 1 = b0, 2 = b1, 3 = a1; each wave stages 16 rows (2 pieces of 8) of every part.
   //      a-part rows r' in [0,128): tile row = r' + 64*ah + (r' >= 64 ? 64 : 0)      (rows of both wave rows' half ah)
   //      b-part rows r' in [0,128): tile row = (r'/32)*64 + 32*bh + r'%32            (rows of all four wave cols' half bh)
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)bidx * g.strideA;
-  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
-  uint32_t src[4][2];     // element offsets from Ab / Wb (both tensors are < 2^31 elements)
+  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)bidx * g.strideA * ESZ;
+  const char* Wb = reinterpret_cast<const char*>(g.W);
+  uint32_t src[4][2];     // byte offsets from Ab / Wb (both tensors are < 2^32 bytes; checked on the host)
   int lds_off[4][2];
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
@@ -313,17 +335,17 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
       const int lc = (lane & 7) ^ ((row >> 1) & 7);
       if (is_a) {
         const int am = min(m0 + row, g.M - 1);
-        src[part][q] = (uint32_t)((int64_t)am * g.lda + lc * 8);
+        src[part][q] = (uint32_t)(((int64_t)am * g.lda) * ESZ + lc * 16);
         lds_off[part][q] = rowbase * 128;
       } else {
         const int wr = min(n0 + row, g.N - 1);
-        src[part][q] = (uint32_t)((int64_t)wr * g.ldw + lc * 8);
+        src[part][q] = (uint32_t)(((int64_t)wr * g.ldw) * ESZ + lc * 16);
         lds_off[part][q] = TILE_BYTES + rowbase * 128;
       }
     }
   }
-  auto issue = [&](int part, int buf, int koff) {
-    const bf16_t* base = ((part == 0 || part == 3) ? Ab : Wb) + koff;     // wave-uniform (SGPR) base + per-lane 32-bit offset
+  auto issue = [&](int part, int buf, int koff) {                        // koff in BYTES along the row
+    const char* base = ((part == 0 || part == 3) ? Ab : Wb) + koff;       // wave-uniform (SGPR) base + per-lane 32-bit offset
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       __builtin_amdgcn_global_load_lds(GLB_PTR(base + src[part][q]), LDS_PTR(smem + buf * BUF_BYTES + lds_off[part][q]), 16, 0, 0);
@@ -354,18 +376,27 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
     wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd0);                      \
     wf[bh][j][1] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd1);                      \
   }
+#define RT_CAT8(lo, hi) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7)
 #define RT_MFMA(ah, bh)                                                                                           \
   do {                                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+    if constexpr (FP8) {                                                                                          \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-          acc[(ah)*4 + i][(bh)*2 + j] =                                                                           \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \
+          acc[(ah)*4 + i][(bh)*2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                         \
+              RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*4 + i][(bh)*2 + j],      \
+              0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* 2^0 */, 0, 0x7F7F7F7F);                            \
+    } else {                                                                                                      \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+            acc[(ah)*4 + i][(bh)*2 + j] =                                                                         \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \
+    }                                                                                                             \
     __builtin_amdgcn_s_setprio(0);                                                                                \
   } while (0)
 
-  const int nk = g.K / BK;
+  const int nk = g.K / BKE;
   issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0); issue(3, 0, 0);
   RT_VMCNT(4);
   RT_BAR();
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
   for (int kt = 0; kt + 1 < nk; ++kt) {
     const char* tb = smem + (kt & 1) * BUF_BYTES;
     const int nb = (kt & 1) ^ 1;
-    const int koff = (kt + 1) * BK;
+    const int koff = (kt + 1) * 128;           // bytes
     // ---- phase 1: (a0,b0)
     RT_READ_A(0); RT_READ_B(0);
     issue(0, nb, koff);
@@ -409,49 +440,66 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_kernel(const Launch L) {
 #undef RT_READ_A
 #undef RT_READ_B
 #undef RT_MFMA
+#undef RT_CAT8
 
   const int mrow = m0 + wm * 128 + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
-  if (g.out_f32) epilogue_tile<true>(g, bidx, mrow, ncol, acc);
-  else epilogue_tile<false>(g, bidx, mrow, ncol, acc);
+  if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc);
 }
 
 }  // namespace
 
-extern "C" int rt_gemm_bf16(const rt_gemm_group* groups, int32_t ngroups, void* stream) {
+static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* stream, bool fp8) {
   if (!groups || ngroups < 1 || ngroups > RT_GEMM_MAX_GROUPS) return RT_E_BADARG;
   Launch L{};
   L.ngroups = ngroups;
   int total = 0;
+  const int bke = fp8 ? 128 : BK;                     // elements per K-tile
+  const int al = fp8 ? 16 : 8;                        // elements per 16 bytes
+  const int64_t esz = fp8 ? 1 : 2;
   for (int i = 0; i < ngroups; ++i) {
     const rt_gemm_group& g = groups[i];
     if (!g.A || !g.W || !g.C || g.M < 1 || g.N < 1 || g.K < 1 || g.batch < 1) return RT_E_BADARG;
-    if (g.K % BK != 0 || g.N % 4 != 0) return RT_E_SHAPE;
+    if (g.K % bke != 0 || g.N % 4 != 0) return RT_E_SHAPE;
     if (g.rows_per_batch > 0 && g.M % g.rows_per_batch != 0) return RT_E_SHAPE;
-    if (!RT_ALIGNED(g.A, 16) || !RT_ALIGNED(g.W, 16) || g.lda % 8 || g.ldw % 8 || g.strideA % 8) return RT_E_ALIGN;
+    if (!RT_ALIGNED(g.A, 16) || !RT_ALIGNED(g.W, 16) || g.lda % al || g.ldw % al || g.strideA % al) return RT_E_ALIGN;
     if (g.lda < g.K || g.ldw < g.K || g.ldc < g.N) return RT_E_SHAPE;
+    // staging offsets are 32-bit byte offsets from the (per-batch) operand base
+    if (((int64_t)g.M * g.lda) * esz >= ((int64_t)1 << 32) || ((int64_t)g.N * g.ldw) * esz >= ((int64_t)1 << 32)) return RT_E_SHAPE;
     const int cal = g.out_f32 ? 16 : 8;
     if (!RT_ALIGNED(g.C, cal) || g.ldc % 4 || g.strideC % 4) return RT_E_ALIGN;
     if (g.res && (!RT_ALIGNED(g.res, cal) || g.ldr % 4 || g.strideR % 4)) return RT_E_ALIGN;
     if (g.add2 && (!RT_ALIGNED(g.add2, 8) || g.ld2 % 4 || g.stride2 % 4)) return RT_E_ALIGN;
     if (g.bias && !RT_ALIGNED(g.bias, 8)) return RT_E_ALIGN;
     if (g.gate && (!RT_ALIGNED(g.gate, 16) || g.gate_ld % 4)) return RT_E_ALIGN;
+    if (fp8 && g.w_scale && !RT_ALIGNED(g.w_scale, 16)) return RT_E_ALIGN;
     L.grp[i].g = g;
     L.grp[i].tiles_m = (g.M + BM - 1) / BM;
     L.grp[i].tiles_n = (g.N + BN - 1) / BN;
     L.grp[i].tile_begin = total;
     total += L.grp[i].tiles_m * L.grp[i].tiles_n * g.batch;
   }
-  static int variant = -1;   // RT_GEMM_VARIANT=simple selects the 2-phase reference schedule (A/B and debugging)
+  static int variant = -1;   // RT_GEMM_VARIANT=simple selects the 2-phase reference schedule (A/B and debugging; bf16 only)
   if (variant < 0) {
     const char* v = getenv("RT_GEMM_VARIANT");
     variant = (v && v[0] == 's') ? 0 : 1;
-    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16_kernel), reinterpret_cast<const void*>(gemm_bf16_simple_kernel)}) {
+    for (const void* f : {reinterpret_cast<const void*>(gemm_pp_kernel<false>), reinterpret_cast<const void*>(gemm_pp_kernel<true>),
+                          reinterpret_cast<const void*>(gemm_bf16_simple_kernel)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (variant == 0) hipLaunchKernelGGL(gemm_bf16_simple_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
-  else hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  if (fp8) hipLaunchKernelGGL(gemm_pp_kernel<true>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  else if (variant == 0) hipLaunchKernelGGL(gemm_bf16_simple_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  else hipLaunchKernelGGL(gemm_pp_kernel<false>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
   return rt_hip_status();
+}
+
+extern "C" int rt_gemm_bf16(const rt_gemm_group* groups, int32_t ngroups, void* stream) {
+  return launch_gemm(groups, ngroups, stream, false);
+}
+
+extern "C" int rt_gemm_fp8(const rt_gemm_group* groups, int32_t ngroups, void* stream) {
+  return launch_gemm(groups, ngroups, stream, true);
 }

@@ -8,11 +8,23 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm (no affine) + (1+scale)·x + shift. One wave per row, row kept in registers (single HBM read).
 // ---------------------------------------------------------------------------------------------------
-template <bool X_F32, int NCH>   // NCH = chunks of 8 elements per lane  (D <= 64*8*NCH)
+// 8 floats -> 8 e4m3 bytes (OCP e4m3fn on gfx950), inputs already divided by the row scale and clamped to +-448
+__device__ __forceinline__ u32x2 pack_e4m3x8(const float (&y)[8]) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
+  return u32x2{(uint32_t)lo, (uint32_t)hi};
+}
+
+constexpr float E4M3_MAX = 448.f;
+
+template <bool X_F32, int NCH, bool OUT_FP8 = false>   // NCH = chunks of 8 elements per lane  (D <= 64*8*NCH)
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(
     const void* __restrict__ x, int64_t ldx, int64_t stride_xb, bf16_t* __restrict__ out, int64_t ldo,
     int64_t stride_ob, const float* __restrict__ shift, const float* __restrict__ scale, int64_t mod_ld,
-    int batch, int rows_per_batch, int D, float eps) {
+    int batch, int rows_per_batch, int D, float eps, float* __restrict__ row_scale = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= batch * rows_per_batch) return;
@@ -52,6 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 64 + lane) * 8;
@@ -70,11 +83,75 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(
           y[4 + i] = y[4 + i] * (1.f + s1[i]) + h1[i];
         }
       }
-      u32x4 o;
+      if constexpr (OUT_FP8) {                       // keep the modulated row in registers; quantise after the row max is known
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(y[2 * i], y[2 * i + 1]);
-      *reinterpret_cast<u32x4*>(out + b * stride_ob + (int64_t)r * ldo + col) = o;
+        for (int i = 0; i < 8; ++i) { v[c][i] = y[i]; amax = fmaxf(amax, fabsf(y[i])); }
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(y[2 * i], y[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(out + b * stride_ob + (int64_t)r * ldo + col) = o;
+      }
     }
+  }
+  if constexpr (OUT_FP8) {
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.f / E4M3_MAX) : 1.f;
+    const float inv = 1.f / sc;
+    if (lane == 0) row_scale[row] = sc;
+    uint8_t* o8 = reinterpret_cast<uint8_t*>(out) + b * stride_ob + (int64_t)r * ldo;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = fminf(fmaxf(v[c][i] * inv, -E4M3_MAX), E4M3_MAX);
+        *reinterpret_cast<u32x2*>(o8 + col) = pack_e4m3x8(y);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-wise e4m3 quantisation (weights once at load; activation rows that do not come out of a LayerNorm).
+// One wave per row; rows longer than the register budget are read twice (max pass, then convert pass).
+// ---------------------------------------------------------------------------------------------------
+template <bool X_F32>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const void* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out,
+                                                                int64_t ldo, float* __restrict__ scale, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  auto load8 = [&](int col, float (&y)[8]) {
+    if (X_F32) {
+      const float* p = reinterpret_cast<const float*>(x) + (int64_t)row * ldx + col;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y[i] = a[i]; y[4 + i] = bb[i]; }
+    } else {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(x) + (int64_t)row * ldx + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y[2 * i] = bf16lo(u[i]); y[2 * i + 1] = bf16hi(u[i]); }
+    }
+  };
+  float amax = 0.f;
+  for (int col = lane * 8; col < D; col += 512) {
+    float y[8];
+    load8(col, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(y[i]));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.f / E4M3_MAX) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) scale[row] = sc;
+  for (int col = lane * 8; col < D; col += 512) {
+    float y[8];
+    load8(col, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = fminf(fmaxf(y[i] * inv, -E4M3_MAX), E4M3_MAX);
+    *reinterpret_cast<u32x2*>(out + (int64_t)row * ldo + col) = pack_e4m3x8(y);
   }
 }
 
@@ -373,6 +450,41 @@ int rt_layernorm_modulate(const void* x, int64_t ldx, int64_t stride_xb, int32_t
     else if (nch <= 6) LN_LAUNCH(false, 6); else if (nch <= 8) LN_LAUNCH(false, 8); else LN_LAUNCH(false, 16);
   }
 #undef LN_LAUNCH
+  return rt_hip_status();
+}
+
+int rt_layernorm_modulate_fp8(const void* x, int64_t ldx, int64_t stride_xb, int32_t x_f32, void* out, int64_t ldo,
+                              int64_t stride_ob, float* row_scale, const float* shift, const float* scale, int64_t mod_ld,
+                              int32_t batch, int32_t rows_per_batch, int32_t D, float eps, void* stream) {
+  if (!x || !out || !row_scale || batch < 1 || rows_per_batch < 1 || D < 8) return RT_E_BADARG;
+  if ((shift == nullptr) != (scale == nullptr)) return RT_E_BADARG;
+  if (D % 8 || D > 8192) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8 || stride_xb % 8 || stride_ob % 8) return RT_E_ALIGN;
+  if (scale && (!RT_ALIGNED(scale, 16) || !RT_ALIGNED(shift, 16) || mod_ld % 4)) return RT_E_ALIGN;
+  const int rows = batch * rows_per_batch;
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (D + 511) / 512;
+#define LN8_LAUNCH(F32, N)                                                                                        \
+  hipLaunchKernelGGL((layernorm_mod_kernel<F32, N, true>), grid, block, 0, st, x, ldx, stride_xb, (bf16_t*)out, ldo, \
+                     stride_ob, shift, scale, mod_ld, batch, rows_per_batch, D, eps, row_scale)
+  if (x_f32) {
+    if (nch <= 2) LN8_LAUNCH(true, 2); else if (nch <= 6) LN8_LAUNCH(true, 6); else LN8_LAUNCH(true, 16);
+  } else {
+    if (nch <= 2) LN8_LAUNCH(false, 2); else if (nch <= 6) LN8_LAUNCH(false, 6); else LN8_LAUNCH(false, 16);
+  }
+#undef LN8_LAUNCH
+  return rt_hip_status();
+}
+
+int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, float* scale, int32_t rows,
+                         int32_t D, void* stream) {
+  if (!x || !out || !scale || rows < 1 || D < 8) return RT_E_BADARG;
+  if (D % 8 || D > 65536) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8) return RT_E_ALIGN;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (x_f32) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
+  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
   return rt_hip_status();
 }
 

@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -41,6 +41,7 @@ class GemmGroup(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("rows_per_batch", C.c_int32), ("gelu_from", C.c_int32), ("out_f32", C.c_int32),
         ("alpha", C.c_float),
+        ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
     ]
 
 
@@ -50,6 +51,9 @@ _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     "rt_abi_version": [],
     "rt_gemm_bf16": [C.POINTER(GemmGroup), _i32, _vp],
+    "rt_gemm_fp8": [C.POINTER(GemmGroup), _i32, _vp],
+    "rt_quantize_rows_fp8": [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp],
+    "rt_layernorm_modulate_fp8": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_gemv_bf16w": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_timestep_embedding": [_vp, _vp, _i32, _i32, _vp],
     "rt_rope_table": [_vp, _vp, _vp, _i32, C.POINTER(_i32), _f32, _vp],

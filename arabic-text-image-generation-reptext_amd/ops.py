@@ -15,6 +15,7 @@ from . import native
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FP8 = torch.float8_e4m3fn        # OCP e4m3 (what gfx950's conversion and MFMA instructions use)
 
 
 def _stream() -> int:
@@ -72,6 +73,13 @@ class LinearProblem:
     rows_per_batch: int = 0
     gelu_from: Optional[int] = None
     alpha: float = 1.0
+    # fp8 problems (rt_gemm_fp8): a and w are float8_e4m3fn, a_scale f32 [B*M] (one per activation row), w_scale f32 [N]
+    a_scale: Optional[torch.Tensor] = None
+    w_scale: Optional[torch.Tensor] = None
+
+    @property
+    def is_fp8(self) -> bool:
+        return self.a.dtype == FP8
 
     def to_group(self) -> native.GemmGroup:
         Bt, M, K, lda, sA = _batched(self.a, "a")
@@ -80,8 +88,20 @@ class LinearProblem:
         if Kw != K or Mo != M or No != N or Bo != Bt:
             raise ValueError(f"linear shapes mismatch: a{tuple(self.a.shape)} w{tuple(self.w.shape)} out{tuple(self.out.shape)}")
         g = native.GemmGroup()
-        g.A = _dev(self.a, "a", BF16)
-        g.W = _dev(self.w, "w", BF16)
+        op_dtype = FP8 if self.is_fp8 else BF16
+        g.A = _dev(self.a, "a", op_dtype)
+        g.W = _dev(self.w, "w", op_dtype)
+        if self.is_fp8:
+            if self.a_scale is not None:
+                if self.a_scale.numel() != Bt * M or not self.a_scale.is_contiguous():
+                    raise ValueError("a_scale must be contiguous with batch*M elements")
+                g.a_scale = _dev(self.a_scale, "a_scale", F32)
+            if self.w_scale is not None:
+                if self.w_scale.numel() != N or not self.w_scale.is_contiguous():
+                    raise ValueError("w_scale must be contiguous with N elements")
+                g.w_scale = _dev(self.w_scale, "w_scale", F32)
+        elif self.a_scale is not None or self.w_scale is not None:
+            raise TypeError("a_scale / w_scale belong to fp8 problems")
         if self.out.dtype not in (BF16, F32):
             raise TypeError("out must be bf16 or f32")
         g.C = _dev(self.out, "out")
@@ -128,7 +148,13 @@ def linear_grouped(problems: Sequence[LinearProblem]) -> None:
     if not 1 <= n <= native.RT_GEMM_MAX_GROUPS:
         raise ValueError(f"1..{native.RT_GEMM_MAX_GROUPS} problems per launch")
     arr = (native.GemmGroup * n)(*[p.to_group() for p in problems])
-    native.check("rt_gemm_bf16", native.load().rt_gemm_bf16(arr, n, _stream()))
+    fp8 = problems[0].is_fp8
+    if any(p.is_fp8 != fp8 for p in problems):
+        raise TypeError("all problems of one launch must have the same operand dtype")
+    if fp8:
+        native.check("rt_gemm_fp8", native.load().rt_gemm_fp8(arr, n, _stream()))
+    else:
+        native.check("rt_gemm_bf16", native.load().rt_gemm_bf16(arr, n, _stream()))
 
 
 def linear(a, w, out, **kw) -> torch.Tensor:
@@ -189,6 +215,40 @@ def layernorm_modulate(x: torch.Tensor, out: torch.Tensor, shift: Optional[torch
         _dev(x, "x"), x.stride(1), x.stride(0), int(x.dtype == F32), _dev(out, "out", BF16), out.stride(1), out.stride(0),
         _opt(shift, "shift", F32), _opt(scale, "scale", F32), mod_ld, B, R, D, float(eps), _stream()))
     return out
+
+
+def layernorm_modulate_fp8(x: torch.Tensor, out: torch.Tensor, row_scale: torch.Tensor, shift: Optional[torch.Tensor],
+                           scale: Optional[torch.Tensor], eps: float = 1e-6) -> torch.Tensor:
+    """As layernorm_modulate, quantising each modulated row to e4m3: out [B,R,D] float8_e4m3fn, row_scale f32 [B*R] contiguous
+    (row b*R + r) — the A operand and a_scale of an fp8 LinearProblem."""
+    if x.dim() != 3 or out.dim() != 3 or x.shape != out.shape or x.stride(2) != 1 or out.stride(2) != 1:
+        raise ValueError("layernorm_modulate_fp8: x/out must be [B,R,D] with unit inner stride")
+    B, R, D = x.shape
+    if row_scale.numel() != B * R or not row_scale.is_contiguous():
+        raise ValueError("row_scale must be contiguous with B*R elements")
+    mod_ld = 0
+    if scale is not None:
+        if scale.shape != (B, D) or shift.shape != (B, D) or scale.stride(1) != 1 or shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("shift/scale must be [B,D] views with equal row stride")
+        mod_ld = scale.stride(0)
+    if x.dtype not in (BF16, F32):
+        raise TypeError("x must be bf16 or f32")
+    native.check("rt_layernorm_modulate_fp8", native.load().rt_layernorm_modulate_fp8(
+        _dev(x, "x"), x.stride(1), x.stride(0), int(x.dtype == F32), _dev(out, "out", FP8), out.stride(1), out.stride(0),
+        _dev(row_scale, "row_scale", F32), _opt(shift, "shift", F32), _opt(scale, "scale", F32), mod_ld, B, R, D, float(eps), _stream()))
+    return out
+
+
+def quantize_rows_fp8(x: torch.Tensor):
+    """x [rows, D] bf16|f32 (unit inner stride) -> (e4m3 [rows, D], scale f32 [rows]) with x ≈ q * scale[:, None]."""
+    rows, D, ldx = _rowmajor2d(x, "x")
+    if x.dtype not in (BF16, F32):
+        raise TypeError("x must be bf16 or f32")
+    q = torch.empty(rows, D, device=x.device, dtype=FP8)
+    sc = torch.empty(rows, device=x.device, dtype=F32)
+    native.check("rt_quantize_rows_fp8", native.load().rt_quantize_rows_fp8(
+        _dev(x, "x"), ldx, int(x.dtype == F32), q.data_ptr(), D, sc.data_ptr(), rows, D, _stream()))
+    return q, sc
 
 
 def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_txt, wk_txt, wq_img, wk_img,

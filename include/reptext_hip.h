@@ -71,9 +71,25 @@ typedef struct rt_gemm_group {
   int32_t gelu_from;    /* first column that gets GELU-tanh; >= N => none */
   int32_t out_f32;      /* C/res dtype: 0 bf16, 1 f32     */
   float alpha;
+  /* fp8 operands (rt_gemm_fp8 only; ignored by rt_gemm_bf16): A and W hold OCP e4m3 bytes, lda/ldw/strideA count
+   * BYTES = elements, K % 128 == 0, and the product is de-quantised before the bias:
+   *   acc[m][n] * a_scale[b*M + m] * w_scale[n]      (either pointer may be NULL = 1.0) */
+  const float* a_scale; /* f32 [batch*M], one per activation row (rt_layernorm_modulate_fp8 / rt_quantize_rows_fp8) */
+  const float* w_scale; /* f32 [N], one per output channel (rt_quantize_rows_fp8 on the weight rows)              */
 } rt_gemm_group;
 
 int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
+
+/* Same contraction and epilogue on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, fp32 accumulate, block scales fixed to
+ * 1.0): BASELINE config 5 ("fp8 weights"), the projections fed by LayerNorm (to_q/k/v, add_*_proj, ff.net.0, proj_mlp).
+ * Tiling, LDS image and schedule are those of rt_gemm_bf16 with a 128-element K-tile (the same 128-byte tile rows). */
+int rt_gemm_fp8(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
+
+/* Row-wise e4m3 quantisation: scale[r] = max|x[r][:]| / 448 (1.0 for an all-zero row), out[r][c] = e4m3(x[r][c] / scale[r]).
+ * x bf16 (x_f32 = 0) or f32 [rows][ldx], out bytes [rows][ldo]; D % 8 == 0, D <= 65536. Used once per weight matrix (rows =
+ * output channels) and for activation rows that do not come out of a LayerNorm. */
+int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, float* scale,
+                         int32_t rows, int32_t D, void* stream);
 
 /* Small-M linear on fp32 activations, bf16 weights (adaLN modulation, time/guidance/pooled MLPs):
  *   y[b][n] (+)= post( Σ_k pre(x[b][k]) · W[n][k] + bias[n] ),  pre/post ∈ {identity, SiLU}
@@ -100,6 +116,12 @@ int rt_layernorm_modulate(const void* x, int64_t ldx, int64_t stride_xb, int32_t
                           void* out, int64_t ldo, int64_t stride_ob,
                           const float* shift, const float* scale, int64_t mod_ld,
                           int32_t batch, int32_t rows_per_batch, int32_t D, float eps, void* stream);
+/* Same, quantising the modulated row to e4m3 on the way out: out bytes [rows][ldo] and row_scale f32 [batch*rows_per_batch]
+ * (= max|y| / 448 of that row), the A operand and a_scale of rt_gemm_fp8. One HBM read of x, half the write bytes. */
+int rt_layernorm_modulate_fp8(const void* x, int64_t ldx, int64_t stride_xb, int32_t x_f32,
+                              void* out, int64_t ldo, int64_t stride_ob, float* row_scale,
+                              const float* shift, const float* scale, int64_t mod_ld,
+                              int32_t batch, int32_t rows_per_batch, int32_t D, float eps, void* stream);
 
 /* RMSNorm(Dh, weight, eps) on q and k heads + interleaved-pair RoPE, in place on a fused
  * projection buffer (A.1 steps 3,5; A.2). Row (b,s) holds q at column q_off and k at k_off,

@@ -251,3 +251,92 @@ def test_euler_pack_cast_mask(ops, gpu):
     assert rel_l2(dy.float().cpu(), y + 0.5 * mask[None, :, None] * xx) < 3e-3
     u = ops.cfg_mix(y.to(gpu, torch.bfloat16), xx.to(gpu, torch.bfloat16), 3.5)
     assert rel_l2(u.float().cpu(), y + 3.5 * (xx - y)) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (BASELINE config 5)
+FP8 = torch.float8_e4m3fn
+
+
+def _quant_rows_ref(x):
+    """The kernel's arithmetic on the CPU: scale = amax/448 (fp32), q = e4m3(clamp(x * (1/scale)))."""
+    x = x.float()
+    amax = x.abs().amax(dim=1)
+    sc = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    y = (x * (1.0 / sc)[:, None]).clamp(-448.0, 448.0)
+    return y.to(FP8), sc
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quantize_rows_fp8(ops, gpu, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(37, 3072, generator=g) * torch.logspace(-3, 2, 37)[:, None]).to(dtype)
+    x[5] = 0                                                          # all-zero row -> scale 1, zeros
+    q, sc = ops.quantize_rows_fp8(x.to(gpu))
+    qr, scr = _quant_rows_ref(x)
+    assert torch.equal(sc.cpu(), scr)
+    a, b = q.cpu().view(torch.uint8), qr.view(torch.uint8)
+    mism = (a != b)
+    # identical arithmetic on both sides; tolerate the odd last-place tie between the device reciprocal and the host's
+    assert mism.float().mean() < 1e-3, float(mism.float().mean())
+    assert rel_l2(q.cpu().float() * sc.cpu()[:, None], x.float()) < 4e-2      # e4m3: 3 mantissa bits
+    assert float(q.cpu().float().abs().max()) <= 448.0
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(256, 256, 128, 1), (300, 520, 384, 1), (512, 768, 3072, 2)])
+def test_gemm_fp8_exact_operands(ops, gpu, M, N, K, batch):
+    """e4m3 x e4m3 products are exact in fp32, so with f32 output the kernel must match an fp32 matmul of the de-quantised
+    operands to accumulation-order noise: this pins the operand layout of v_mfma_scale_f32_16x16x128_f8f6f4 (each lane
+    group's 32 k-values are taken as chunks j and j+4 of the 128-byte tile row, for both operands)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a8 = torch.randn(batch, M, K, generator=g).to(FP8)
+    w8 = (torch.randn(N, K, generator=g) * 0.5).to(FP8)
+    sa = torch.rand(batch * M, generator=g) + 0.5
+    sw = torch.rand(N, generator=g) * 0.02 + 0.01
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+    ref = torch.einsum("bmk,nk->bmn", a8.float().double(), w8.float().double()) * sa.view(batch, M, 1).double() * sw.view(1, 1, N).double() + bias.double()
+    out = torch.empty(batch, M, N, device=gpu, dtype=torch.float32)
+    ops.linear(a8.to(gpu), w8.to(gpu), out, bias=bias.to(gpu), a_scale=sa.to(gpu), w_scale=sw.to(gpu))
+    err = rel_l2(out.cpu(), ref)
+    print(f"gemm fp8 {M}x{N}x{K} b{batch} f32-out rel-L2 {err:.2e}")
+    assert err < 2e-5
+    # bf16 output + GELU on the upper columns + grouped launch with a second problem (image + text stream shape)
+    out16 = torch.empty(batch, M, N, device=gpu, dtype=torch.bfloat16)
+    a2 = torch.randn(1, 64, K, generator=g).to(FP8)
+    out2 = torch.empty(1, 64, N, device=gpu, dtype=torch.bfloat16)
+    ops.linear_grouped([ops.LinearProblem(a8.to(gpu), w8.to(gpu), out16, bias=bias.to(gpu), a_scale=sa.to(gpu), w_scale=sw.to(gpu), gelu_from=N // 2),
+                        ops.LinearProblem(a2.to(gpu), w8.to(gpu), out2, w_scale=sw.to(gpu))])
+    refg = ref.clone()
+    refg[..., N // 2:] = orc.gelu_tanh(ref[..., N // 2:].float()).double()
+    assert rel_l2(out16.float().cpu(), refg) < 3e-3
+    ref2 = torch.einsum("bmk,nk->bmn", a2.float().double(), w8.float().double()) * sw.view(1, 1, N).double()
+    assert rel_l2(out2.float().cpu(), ref2) < 3e-3
+
+
+def test_gemm_fp8_rejects_bad_shapes(ops, gpu):
+    from reptext_amd import native
+
+    a = torch.zeros(64, 192, device=gpu, dtype=FP8)           # K % 128 != 0
+    w = torch.zeros(64, 192, device=gpu, dtype=FP8)
+    with pytest.raises(native.NativeCallError):
+        ops.linear(a, w, torch.empty(64, 64, device=gpu, dtype=torch.bfloat16))
+    with pytest.raises(TypeError):                             # mixed operand dtypes
+        ops.linear(torch.zeros(64, 256, device=gpu, dtype=FP8), torch.zeros(64, 256, device=gpu, dtype=torch.bfloat16),
+                   torch.empty(64, 64, device=gpu, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("xdtype", [torch.bfloat16, torch.float32])
+def test_layernorm_modulate_fp8(ops, gpu, xdtype):
+    g = torch.Generator().manual_seed(9)
+    B, R, D = 2, 70, 3072
+    x = (torch.randn(B, R, D, generator=g) * 3 + 0.5).to(xdtype)
+    shift, scale = torch.randn(B, D, generator=g) * 0.3, torch.randn(B, D, generator=g) * 0.3
+    y = orc.layer_norm(x.float()) * (1 + scale[:, None]) + shift[:, None]
+    qr, scr = _quant_rows_ref(y.reshape(B * R, D))
+    out = torch.empty(B, R, D, device=gpu, dtype=FP8)
+    rs = torch.empty(B * R, device=gpu, dtype=torch.float32)
+    ops.layernorm_modulate_fp8(x.to(gpu), out, rs, shift.to(gpu), scale.to(gpu))
+    assert rel_l2(rs.cpu(), scr) < 1e-5
+    deq = out.cpu().float().reshape(B * R, D) * rs.cpu()[:, None]
+    assert rel_l2(deq, y.reshape(B * R, D)) < 4e-2                      # e4m3 rounding floor (2^-4 relative, uniform: ~2.6e-2)
+    mism = (out.cpu().view(torch.uint8).reshape(B * R, D) != qr.view(torch.uint8)).float().mean()
+    assert mism < 2e-2, float(mism)                                     # fp32 LN statistics differ in the last place -> a few ties flip
