@@ -58,6 +58,15 @@ class DoublePlan:
     ff1_txt_b: torch.Tensor
     ff2_txt_w: torch.Tensor
     ff2_txt_b: torch.Tensor
+    # e4m3 copies (+ per-output-channel scales) of the projections fed by a LayerNorm; None = bf16 path
+    qkv_img_w8: Optional[torch.Tensor] = None
+    qkv_img_ws: Optional[torch.Tensor] = None
+    qkv_txt_w8: Optional[torch.Tensor] = None
+    qkv_txt_ws: Optional[torch.Tensor] = None
+    ff1_img_w8: Optional[torch.Tensor] = None
+    ff1_img_ws: Optional[torch.Tensor] = None
+    ff1_txt_w8: Optional[torch.Tensor] = None
+    ff1_txt_ws: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -70,6 +79,8 @@ class SinglePlan:
     nk: torch.Tensor
     out_w: torch.Tensor
     out_b: torch.Tensor
+    fused_w8: Optional[torch.Tensor] = None
+    fused_ws: Optional[torch.Tensor] = None
 
 
 def _fuse(lins) -> tuple:
@@ -86,24 +97,33 @@ def _fuse(lins) -> tuple:
     return w, b
 
 
-def plan_double(blk) -> DoublePlan:
+def plan_double(blk, fp8: bool = False) -> DoublePlan:
     a = blk.attn
     qi_w, qi_b = _fuse([a.to_q, a.to_k, a.to_v])
     qt_w, qt_b = _fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
-    return DoublePlan(
+    pl = DoublePlan(
         blk.norm1.linear.weight.data, blk.norm1.linear.bias.data, blk.norm1_context.linear.weight.data,
         blk.norm1_context.linear.bias.data, qi_w, qi_b, qt_w, qt_b, a.norm_q.weight.data, a.norm_k.weight.data,
         a.norm_added_q.weight.data, a.norm_added_k.weight.data, a.to_out[0].weight.data, a.to_out[0].bias.data,
         a.to_add_out.weight.data, a.to_add_out.bias.data, blk.ff.net[0].proj.weight.data, blk.ff.net[0].proj.bias.data,
         blk.ff.net[2].weight.data, blk.ff.net[2].bias.data, blk.ff_context.net[0].proj.weight.data,
         blk.ff_context.net[0].proj.bias.data, blk.ff_context.net[2].weight.data, blk.ff_context.net[2].bias.data)
+    if fp8:
+        pl.qkv_img_w8, pl.qkv_img_ws = ops.quantize_rows_fp8(pl.qkv_img_w)
+        pl.qkv_txt_w8, pl.qkv_txt_ws = ops.quantize_rows_fp8(pl.qkv_txt_w)
+        pl.ff1_img_w8, pl.ff1_img_ws = ops.quantize_rows_fp8(pl.ff1_img_w)
+        pl.ff1_txt_w8, pl.ff1_txt_ws = ops.quantize_rows_fp8(pl.ff1_txt_w)
+    return pl
 
 
-def plan_single(blk) -> SinglePlan:
+def plan_single(blk, fp8: bool = False) -> SinglePlan:
     a = blk.attn
     fw, fb = _fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])
-    return SinglePlan(blk.norm.linear.weight.data, blk.norm.linear.bias.data, fw, fb, a.norm_q.weight.data,
-                      a.norm_k.weight.data, blk.proj_out.weight.data, blk.proj_out.bias.data)
+    pl = SinglePlan(blk.norm.linear.weight.data, blk.norm.linear.bias.data, fw, fb, a.norm_q.weight.data,
+                    a.norm_k.weight.data, blk.proj_out.weight.data, blk.proj_out.bias.data)
+    if fp8:
+        pl.fused_w8, pl.fused_ws = ops.quantize_rows_fp8(pl.fused_w)
+    return pl
 
 
 class Workspace:
@@ -122,6 +142,18 @@ class Workspace:
         self.mod_b = e(B, 6 * d, dt=F32)
         self.temb = e(B, d, dt=F32)
         self.tmp = e(B, d, dt=F32)
+        self._device = device
+        self.xn8 = None                            # fp8 path (allocated on first use): e4m3 LayerNorm output + row scales
+        self.xs_t = self.xs_i = self.xs_all = None
+
+    def fp8_buffers(self):
+        if self.xn8 is None:
+            B, T, N, S, d = self.B, self.T, self.N, self.S, self.d
+            self.xn8 = torch.empty(B, S, d, device=self._device, dtype=ops.FP8)
+            self.xs_t = torch.empty(B * T, device=self._device, dtype=F32)
+            self.xs_i = torch.empty(B * N, device=self._device, dtype=F32)
+            self.xs_all = torch.empty(B * S, device=self._device, dtype=F32)
+        return self.xn8
 
 
 _WS_CACHE = {}
@@ -226,11 +258,20 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
         ops.gemv(temb, pl.ada_img_w, pl.ada_img_b, mi, silu_in=True)
         ops.gemv(temb, pl.ada_txt_w, pl.ada_txt_b, mt, silu_in=True)
     ch = lambda m, i: m[:, i * d : (i + 1) * d]
-    # 2. norm + modulate
-    ops.layernorm_modulate(x_i, xn_i, ch(mi, 0), ch(mi, 1))
-    ops.layernorm_modulate(x_t, xn_t, ch(mt, 0), ch(mt, 1))
-    # 3. q,k,v projections of both streams, one launch
-    ops.linear_grouped([P(xn_i, pl.qkv_img_w, ws.qkv[:, T:], bias=pl.qkv_img_b), P(xn_t, pl.qkv_txt_w, ws.qkv[:, :T], bias=pl.qkv_txt_b)])
+    fp8 = pl.qkv_img_w8 is not None
+    if fp8:
+        xn8 = ws.fp8_buffers()
+        xn8_t, xn8_i = xn8[:, :T], xn8[:, T:]
+    # 2. norm + modulate, 3. q,k,v projections of both streams, one launch
+    if fp8:
+        ops.layernorm_modulate_fp8(x_i, xn8_i, ws.xs_i, ch(mi, 0), ch(mi, 1))
+        ops.layernorm_modulate_fp8(x_t, xn8_t, ws.xs_t, ch(mt, 0), ch(mt, 1))
+        ops.linear_grouped([P(xn8_i, pl.qkv_img_w8, ws.qkv[:, T:], bias=pl.qkv_img_b, a_scale=ws.xs_i, w_scale=pl.qkv_img_ws),
+                            P(xn8_t, pl.qkv_txt_w8, ws.qkv[:, :T], bias=pl.qkv_txt_b, a_scale=ws.xs_t, w_scale=pl.qkv_txt_ws)])
+    else:
+        ops.layernorm_modulate(x_i, xn_i, ch(mi, 0), ch(mi, 1))
+        ops.layernorm_modulate(x_t, xn_t, ch(mt, 0), ch(mt, 1))
+        ops.linear_grouped([P(xn_i, pl.qkv_img_w, ws.qkv[:, T:], bias=pl.qkv_img_b), P(xn_t, pl.qkv_txt_w, ws.qkv[:, :T], bias=pl.qkv_txt_b)])
     # 4.-5. RMSNorm(q,k) + RoPE in place
     ops.qk_rmsnorm_rope(ws.qkv, 0, d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin)
     # 6. joint attention; output over q
@@ -239,10 +280,16 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     # 7./8. x += gate_msa * out_proj(attn)
     ops.linear_grouped([P(q[:, T:], pl.out_img_w, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i),
                         P(q[:, :T], pl.out_txt_w, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t)])
-    ops.layernorm_modulate(x_i, xn_i, ch(mi, 3), ch(mi, 4))
-    ops.layernorm_modulate(x_t, xn_t, ch(mt, 3), ch(mt, 4))
-    ops.linear_grouped([P(xn_i, pl.ff1_img_w, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0),
-                        P(xn_t, pl.ff1_txt_w, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0)])
+    if fp8:
+        ops.layernorm_modulate_fp8(x_i, xn8_i, ws.xs_i, ch(mi, 3), ch(mi, 4))
+        ops.layernorm_modulate_fp8(x_t, xn8_t, ws.xs_t, ch(mt, 3), ch(mt, 4))
+        ops.linear_grouped([P(xn8_i, pl.ff1_img_w8, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0, a_scale=ws.xs_i, w_scale=pl.ff1_img_ws),
+                            P(xn8_t, pl.ff1_txt_w8, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0, a_scale=ws.xs_t, w_scale=pl.ff1_txt_ws)])
+    else:
+        ops.layernorm_modulate(x_i, xn_i, ch(mi, 3), ch(mi, 4))
+        ops.layernorm_modulate(x_t, xn_t, ch(mt, 3), ch(mt, 4))
+        ops.linear_grouped([P(xn_i, pl.ff1_img_w, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0),
+                            P(xn_t, pl.ff1_txt_w, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0)])
     ops.linear_grouped([P(ws.ffh[:, T:], pl.ff2_img_w, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject),
                         P(ws.ffh[:, :T], pl.ff2_txt_w, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t)])
 
@@ -256,9 +303,14 @@ def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     else:
         m = ws.mod_a[:, : 3 * d]
         ops.gemv(temb, pl.ada_w, pl.ada_b, m, silu_in=True)                   # shift, scale, gate
-    ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
     big = ws.big
-    ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)        # [k|v|q|gelu(mlp)]
+    if pl.fused_w8 is not None:
+        xn8 = ws.fp8_buffers()
+        ops.layernorm_modulate_fp8(ws.x, xn8, ws.xs_all, m[:, :d], m[:, d : 2 * d])
+        ops.linear(xn8, pl.fused_w8, big, bias=pl.fused_b, gelu_from=3 * d, a_scale=ws.xs_all, w_scale=pl.fused_ws)
+    else:
+        ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
+        ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)    # [k|v|q|gelu(mlp)]
     ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
     q = big[..., 2 * d : 3 * d]
     ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)

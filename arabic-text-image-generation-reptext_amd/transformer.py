@@ -74,7 +74,8 @@ class _MMDiTBase(nn.Module, WeightsIO):
             raise TypeError(f"{type(self).__name__}: HIP path computes in bf16 storage; got {self.dtype}. Use torch_dtype=torch.bfloat16.")
         if not self.x_embedder.weight.is_cuda:
             raise RuntimeError(f"{type(self).__name__} is on {self.device}; move it to the GPU (.to('cuda')). There is no CPU fallback.")
-        self._plans = ([mmdit.plan_double(b) for b in self.transformer_blocks], [mmdit.plan_single(b) for b in self.single_transformer_blocks])
+        fp8 = getattr(self, "_fp8_linears", False)
+        self._plans = ([mmdit.plan_double(b, fp8) for b in self.transformer_blocks], [mmdit.plan_single(b, fp8) for b in self.single_transformer_blocks])
         self._plan_key = key
         self._rope_cache = {}
         return self._plans
@@ -83,8 +84,20 @@ class _MMDiTBase(nn.Module, WeightsIO):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
+    def enable_fp8_linears(self, on: bool = True):
+        """BASELINE config 5 ("fp8 weights"): run the projections that read a LayerNorm output — to_q/k/v, add_q/k/v_proj,
+        ff.net.0, ff_context.net.0, proj_mlp (58 % of the block's GEMM FLOPs) — on the e4m3 MFMA path. Weights are quantised
+        per output channel when the plans are (re)built, activations per token inside the LayerNorm kernel; everything else
+        (attention, out/down projections, residual stream, adaLN) is unchanged. Accuracy: e4m3 carries 3 mantissa bits —
+        see DESIGN.md §4 for the measured floor."""
+        self._fp8_linears = bool(on)
+        self._plans = None
+        return self
+
     def load_state_dict(self, sd, strict: bool = True, **kw):
         out = super().load_state_dict(sd, strict=strict, **kw)
+        if getattr(self, "_fp8_linears", False):
+            self._plans = None          # the e4m3 copies of the weights are stale
         return out
 
     def _rope(self, txt_ids: torch.Tensor, img_ids: torch.Tensor):

@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--inference-steps", type=int, default=28)
     ap.add_argument("--text-lines", type=int, default=1)
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
+                    help="bf16 = BASELINE config 2 (the headline); fp8 = config 5's 'fp8 weights': LayerNorm-fed projections on the e4m3 MFMA path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="DEBUG ONLY: scale layer counts (result flagged invalid)")
@@ -78,7 +80,7 @@ class GemmTimer:
 
     def __init__(self, ops_mod):
         self.ops = ops_mod
-        self.events, self.flops = [], []
+        self.events, self.flops, self.fp8 = [], [], []
         self._orig = None
 
     def __enter__(self):
@@ -97,6 +99,7 @@ class GemmTimer:
             e1.record()
             self.events.append((e0, e1))
             self.flops.append(fl)
+            self.fp8.append(bool(problems[0].is_fp8))
 
         ops.linear_grouped = timed
         return self
@@ -104,10 +107,12 @@ class GemmTimer:
     def __exit__(self, *a):
         self.ops.linear_grouped = self._orig
 
-    def result(self):
+    def result(self, fp8=None):
+        """(launches, flops, seconds) of all GEMM launches, or only the e4m3 (fp8=True) / bf16 (fp8=False) ones."""
         torch.cuda.synchronize()
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
-        return len(self.events), sum(self.flops), tot_ms * 1e-3
+        sel = [i for i in range(len(self.events)) if fp8 is None or self.fp8[i] == fp8]
+        tot_ms = sum(self.events[i][0].elapsed_time(self.events[i][1]) for i in sel)
+        return len(sel), sum(self.flops[i] for i in sel), tot_ms * 1e-3
 
 
 def pmc_traffic_bytes(kernel_key: str):
@@ -219,6 +224,9 @@ def main():
     tkw = {k: v for k, v in cfg_t.items()}
     transformer = FluxTransformer2DModel(**tkw, device=dev, dtype=bf16).random_init_(seed=0)
     controlnet = FluxControlNetModel(**cfg_c, device=dev, dtype=bf16).random_init_(seed=1)   # zero-linears random too
+    if args.precision == "fp8":
+        transformer.enable_fp8_linears(True)
+        controlnet.enable_fp8_linears(True)
     vae = AutoencoderKL(**flux_vae_config(), device=dev, dtype=bf16).random_init_(seed=2)
     pipe = FluxControlNetPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=None, tokenizer=None,
                                   text_encoder_2=None, tokenizer_2=None, transformer=transformer, controlnet=controlnet)
@@ -286,13 +294,22 @@ def main():
     if rank == 0 and not args.no_roofline_pass:
         with GemmTimer(ops) as gt:
             one_pass(10 ** 6)
-        n_launch, fl, sec = gt.result()
+        if args.precision == "bf16":
+            n_launch, fl, sec = gt.result()
+            peak, kname, tkey = 2500.0, "gemm_pp_kernel<bf16> (rt_gemm_bf16)", "gemm"
+        else:                                    # dominant kernel of the fp8 run: the e4m3 instantiation, priced at the dense fp8 peak
+            n_launch, fl, sec = gt.result(fp8=True)
+            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", None
         ach = fl / sec / 1e12
-        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                    "traffic": pmc_traffic_bytes("gemm"), "kernel": "gemm_bf16_kernel", "launches": n_launch,
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc_traffic_bytes(tkey) if tkey else None, "kernel": kname, "launches": n_launch,
                     "avg_launch_us": round(sec / n_launch * 1e6, 2), "avg_gflop_per_launch": round(fl / n_launch / 1e9, 2),
                     "e2e_tflops_per_gpu": round(fl_img * Bl * args.steps / elapsed / 1e12, 1),
                     "e2e_frac": round(fl_img * Bl * args.steps / elapsed / 2.5e15, 4)}
+        if args.precision != "bf16":
+            nb, flb, secb = gt.result(fp8=False)
+            roofline["bf16_gemm_launches"] = {"launches": nb, "achieved": round(flb / secb / 1e12, 1), "peak": 2500.0,
+                                              "frac": round(flb / secb / 2.5e15, 4), "share_of_gemm_time": round(secb / (sec + secb), 3)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg_t, H, W, args.inference_steps, args.text_lines, cfg_c)
@@ -304,7 +321,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "sec_per_image": round(elapsed / (args.steps * Bl), 4),
             "loop_only_ms_per_step": None if loop_ms is None else round(loop_ms, 2),          # rank 0, median over the timed passes
             "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16", "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
                        "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},

@@ -39,9 +39,43 @@ def stored_as(dtype: Optional[torch.dtype]):
         _STORE = prev
 
 
+# fp8 emulation (BASELINE config 5, off by default): under `fp8_linears()` the projections the HIP path runs on the e4m3 MFMA
+# (those fed by a LayerNorm) see their input quantised per token and their weight per output channel, exactly as
+# rt_layernorm_modulate_fp8 / rt_quantize_rows_fp8 do: scale = amax / 448, q = e4m3(x / scale), product de-quantised in fp32.
+_FP8 = False
+_FP8_SUFFIXES = (".attn.to_q", ".attn.to_k", ".attn.to_v", ".attn.add_q_proj", ".attn.add_k_proj", ".attn.add_v_proj",
+                 ".ff.net.0.proj", ".ff_context.net.0.proj", ".proj_mlp")
+
+
+@contextlib.contextmanager
+def fp8_linears(on: bool = True):
+    global _FP8
+    prev, _FP8 = _FP8, on
+    try:
+        yield
+    finally:
+        _FP8 = prev
+
+
+def quant_rows_e4m3(x: torch.Tensor) -> torch.Tensor:
+    """Quantise-dequantise along the last dim with one scale per row (restates csrc/norm_elem.hip's arithmetic)."""
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    q = (x * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return q * sc
+
+
+def _ln_out(x: torch.Tensor) -> torch.Tensor:
+    """LayerNorm-modulate output: stored as bf16 on the bf16 path, quantised straight from fp32 on the fp8 path."""
+    return x if _FP8 else _s(x)
+
+
 # --------------------------------------------------------------------------------------- primitives
 def linear(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
-    return F.linear(x, p[name + ".weight"], p.get(name + ".bias"))
+    w = p[name + ".weight"]
+    if _FP8 and name.endswith(_FP8_SUFFIXES):
+        return F.linear(quant_rows_e4m3(x), quant_rows_e4m3(w), p.get(name + ".bias"))
+    return F.linear(x, w, p.get(name + ".bias"))
 
 
 def layer_norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
@@ -124,8 +158,8 @@ def double_block(p: Params, pre: str, h, e, temb, rope, H: int = 24, Dh: int = 1
     cos, sin = rope
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = linear(p, f"{pre}.norm1.linear", silu(temb)).chunk(6, dim=-1)
     csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = linear(p, f"{pre}.norm1_context.linear", silu(temb)).chunk(6, dim=-1)
-    nh = _s(layer_norm(h) * (1 + sc_a[:, None]) + sh_a[:, None])
-    ne = _s(layer_norm(e) * (1 + csc_a[:, None]) + csh_a[:, None])
+    nh = _ln_out(layer_norm(h) * (1 + sc_a[:, None]) + sh_a[:, None])
+    ne = _ln_out(layer_norm(e) * (1 + csc_a[:, None]) + csh_a[:, None])
 
     def heads(x):
         return _s(x).reshape(x.shape[0], x.shape[1], H, Dh)
@@ -147,9 +181,9 @@ def double_block(p: Params, pre: str, h, e, temb, rope, H: int = 24, Dh: int = 1
         return linear(p, f"{pre}.{name}.net.2", _s(gelu_tanh(linear(p, f"{pre}.{name}.net.0.proj", x))))
 
     h = h + g_a[:, None] * a_h
-    h = h + g_m[:, None] * ff("ff", _s(layer_norm(h) * (1 + sc_m[:, None]) + sh_m[:, None]))
+    h = h + g_m[:, None] * ff("ff", _ln_out(layer_norm(h) * (1 + sc_m[:, None]) + sh_m[:, None]))
     e = e + cg_a[:, None] * a_e
-    e = e + cg_m[:, None] * ff("ff_context", _s(layer_norm(e) * (1 + csc_m[:, None]) + csh_m[:, None]))
+    e = e + cg_m[:, None] * ff("ff_context", _ln_out(layer_norm(e) * (1 + csc_m[:, None]) + csh_m[:, None]))
     return e, h
 
 
@@ -158,7 +192,7 @@ def single_block(p: Params, pre: str, x, temb, rope, H: int = 24, Dh: int = 128)
     B, S, d = x.shape
     cos, sin = rope
     sh, sc, g = linear(p, f"{pre}.norm.linear", silu(temb)).chunk(3, dim=-1)
-    nx = _s(layer_norm(x) * (1 + sc[:, None]) + sh[:, None])
+    nx = _ln_out(layer_norm(x) * (1 + sc[:, None]) + sh[:, None])
     m = _s(gelu_tanh(linear(p, f"{pre}.proj_mlp", nx)))
     q = rms_norm(_s(linear(p, f"{pre}.attn.to_q", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_q.weight"])
     k = rms_norm(_s(linear(p, f"{pre}.attn.to_k", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_k.weight"])

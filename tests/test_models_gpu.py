@@ -150,3 +150,45 @@ def test_models_refuse_cpu(gpu):
     with pytest.raises(RuntimeError):
         tr(hidden_states=x["latents"].bfloat16(), encoder_hidden_states=x["prompt"].bfloat16(), pooled_projections=x["pooled"].bfloat16(),
            timestep=x["timestep"], img_ids=x["img_ids"], txt_ids=x["txt_ids"], guidance=x["guidance"])
+
+
+def test_fp8_linears_transformer_and_tower(gpu):
+    """BASELINE config 5 ("fp8 weights"): LayerNorm-fed projections on the e4m3 MFMA path. Comparator: the oracle with the same
+    quantisation points (`fp8_linears()` + bf16 storage); the GPU must sit on that run's floor, and the floor itself is
+    printed against the fp32 oracle (random-init weights: the residual stream's skip path attenuates the 3-bit noise)."""
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    tp = orc.init_mmdit_params(SMALL_T, seed=71)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=72, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    x = make_inputs(2, 64, 16, 24, seed=7)
+    d = to_dev(x, gpu)
+    targs = (tp, SMALL_T, x["latents"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"], x["txt_ids"])
+    call_t = lambda: tr(hidden_states=d["latents"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["timestep"],
+                        img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0].float().cpu()
+    out16 = call_t()
+    tr.enable_fp8_linears(True)
+    out8 = call_t()
+    assert not torch.equal(out8, out16)                                   # the other path really ran
+    ref = orc.transformer_forward(*targs, guidance=x["guidance"])
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears():
+        ref8 = orc.transformer_forward(*targs, guidance=x["guidance"])
+    err, err8, floor = rel_l2(out8, ref), rel_l2(out8, ref8), rel_l2(ref8, ref)
+    print(f"fp8 transformer rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e}; bf16 path {rel_l2(out16, ref):.3e})")
+    assert_at_dtype_floor(err, err8, floor)
+    assert err < 3e-2
+    tr.enable_fp8_linears(False)
+    assert torch.equal(call_t(), out16)                                   # and switching back restores the bf16 path bit for bit
+    # tower
+    cn.enable_fp8_linears(True)
+    bs, ss = cn(hidden_states=d["latents"], controlnet_cond=d["cond"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"],
+                timestep=d["timestep"], img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)
+    cargs = (cp, SMALL_CN, x["latents"], x["cond"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"], x["txt_ids"])
+    rb, rs = orc.controlnet_forward(*cargs, guidance=x["guidance"])
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears():
+        rb8, rs8 = orc.controlnet_forward(*cargs, guidance=x["guidance"])
+    for a, b, b8 in zip(bs + ss, rb + rs, rb8 + rs8):
+        assert_at_dtype_floor(rel_l2(a.float().cpu(), b), rel_l2(a.float().cpu(), b8), rel_l2(b8, b))

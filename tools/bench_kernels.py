@@ -42,6 +42,26 @@ def bench_gemm():
     print(f"grouped qkv (4096+512)x9216x3072: {t*1e6:9.1f} us  {2*(T+Ni)*3*d*d/t/1e12:8.1f} TF/s", flush=True)
 
 
+def bench_gemm_fp8():
+    FP8 = torch.float8_e4m3fn
+    shapes = [(4608, 21504, 3072), (4096, 9216, 3072), (4096, 12288, 3072), (8192, 8192, 8192), (9728, 21504, 3072)]
+    for M, N, K in shapes:
+        a = torch.randn(M, K, device=dev).to(FP8)
+        w = torch.randn(N, K, device=dev).to(FP8)
+        sa = torch.rand(M, device=dev) + 0.5
+        sw = torch.rand(N, device=dev) * 0.02
+        b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.linear(a, w, out, bias=b, a_scale=sa, w_scale=sw))
+        print(f"gemm fp8 M={M} N={N} K={K}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+    x = torch.randn(1, 4608, 3072, device=dev)
+    o8 = torch.empty(1, 4608, 3072, device=dev, dtype=FP8)
+    rs = torch.empty(4608, device=dev)
+    mod = torch.randn(1, 6144, device=dev)
+    t = timeit(lambda: ops.layernorm_modulate_fp8(x, o8, rs, mod[:, :3072], mod[:, 3072:]))
+    print(f"layernorm_mod_fp8 4608x3072 (f32 in): {t*1e6:8.1f} us", flush=True)
+
+
 def bench_attn():
     for B, S, H in [(1, 4608, 24), (1, 768, 24), (1, 9728, 24)]:
         d = H * 128
@@ -74,6 +94,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("fp8", "all"):
+        bench_gemm_fp8()
     if what in ("attn", "all"):
         bench_attn()
     if what in ("elem", "all"):
