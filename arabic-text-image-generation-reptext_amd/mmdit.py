@@ -67,6 +67,15 @@ class DoublePlan:
     ff1_img_ws: Optional[torch.Tensor] = None
     ff1_txt_w8: Optional[torch.Tensor] = None
     ff1_txt_ws: Optional[torch.Tensor] = None
+    # level "all": also the projections whose input is a bf16 activation (attention output, GELU hidden), quantised by a pass
+    out_img_w8: Optional[torch.Tensor] = None
+    out_img_ws: Optional[torch.Tensor] = None
+    out_txt_w8: Optional[torch.Tensor] = None
+    out_txt_ws: Optional[torch.Tensor] = None
+    ff2_img_w8: Optional[torch.Tensor] = None
+    ff2_img_ws: Optional[torch.Tensor] = None
+    ff2_txt_w8: Optional[torch.Tensor] = None
+    ff2_txt_ws: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -81,6 +90,8 @@ class SinglePlan:
     out_b: torch.Tensor
     fused_w8: Optional[torch.Tensor] = None
     fused_ws: Optional[torch.Tensor] = None
+    out_w8: Optional[torch.Tensor] = None
+    out_ws: Optional[torch.Tensor] = None
 
 
 def _fuse(lins) -> tuple:
@@ -97,7 +108,8 @@ def _fuse(lins) -> tuple:
     return w, b
 
 
-def plan_double(blk, fp8: bool = False) -> DoublePlan:
+def plan_double(blk, fp8=False) -> DoublePlan:
+    """fp8: False | 'ln' (LayerNorm-fed projections) | 'all' (every projection of the block)."""
     a = blk.attn
     qi_w, qi_b = _fuse([a.to_q, a.to_k, a.to_v])
     qt_w, qt_b = _fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
@@ -113,16 +125,23 @@ def plan_double(blk, fp8: bool = False) -> DoublePlan:
         pl.qkv_txt_w8, pl.qkv_txt_ws = ops.quantize_rows_fp8(pl.qkv_txt_w)
         pl.ff1_img_w8, pl.ff1_img_ws = ops.quantize_rows_fp8(pl.ff1_img_w)
         pl.ff1_txt_w8, pl.ff1_txt_ws = ops.quantize_rows_fp8(pl.ff1_txt_w)
+    if fp8 == "all":
+        pl.out_img_w8, pl.out_img_ws = ops.quantize_rows_fp8(pl.out_img_w)
+        pl.out_txt_w8, pl.out_txt_ws = ops.quantize_rows_fp8(pl.out_txt_w)
+        pl.ff2_img_w8, pl.ff2_img_ws = ops.quantize_rows_fp8(pl.ff2_img_w)
+        pl.ff2_txt_w8, pl.ff2_txt_ws = ops.quantize_rows_fp8(pl.ff2_txt_w)
     return pl
 
 
-def plan_single(blk, fp8: bool = False) -> SinglePlan:
+def plan_single(blk, fp8=False) -> SinglePlan:
     a = blk.attn
     fw, fb = _fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])
     pl = SinglePlan(blk.norm.linear.weight.data, blk.norm.linear.bias.data, fw, fb, a.norm_q.weight.data,
                     a.norm_k.weight.data, blk.proj_out.weight.data, blk.proj_out.bias.data)
     if fp8:
         pl.fused_w8, pl.fused_ws = ops.quantize_rows_fp8(pl.fused_w)
+    if fp8 == "all":
+        pl.out_w8, pl.out_ws = ops.quantize_rows_fp8(pl.out_w)
     return pl
 
 
@@ -154,6 +173,12 @@ class Workspace:
             self.xs_i = torch.empty(B * N, device=self._device, dtype=F32)
             self.xs_all = torch.empty(B * S, device=self._device, dtype=F32)
         return self.xn8
+
+    def fp8_wide(self, width: int) -> torch.Tensor:
+        """e4m3 staging for quantised bf16 activations: [B,S,width] view of one buffer sized for the widest use (5d)."""
+        if getattr(self, "_a8", None) is None or self._a8.shape[2] < width:
+            self._a8 = torch.empty(self.B, self.S, max(width, 5 * self.d), device=self._device, dtype=ops.FP8)
+        return self._a8[:, :, :width]
 
 
 _WS_CACHE = {}
@@ -278,8 +303,15 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     q, k, v = ws.qkv[..., :d], ws.qkv[..., d : 2 * d], ws.qkv[..., 2 * d :]
     ops.attention(q, k, v, q, H)
     # 7./8. x += gate_msa * out_proj(attn)
-    ops.linear_grouped([P(q[:, T:], pl.out_img_w, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i),
-                        P(q[:, :T], pl.out_txt_w, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t)])
+    if pl.out_img_w8 is not None:
+        a8 = ws.fp8_wide(d)
+        ops.quantize_rows_fp8_into(q[:, T:], a8[:, T:], ws.xs_i)
+        ops.quantize_rows_fp8_into(q[:, :T], a8[:, :T], ws.xs_t)
+        ops.linear_grouped([P(a8[:, T:], pl.out_img_w8, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i, a_scale=ws.xs_i, w_scale=pl.out_img_ws),
+                            P(a8[:, :T], pl.out_txt_w8, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t, a_scale=ws.xs_t, w_scale=pl.out_txt_ws)])
+    else:
+        ops.linear_grouped([P(q[:, T:], pl.out_img_w, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i),
+                            P(q[:, :T], pl.out_txt_w, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t)])
     if fp8:
         ops.layernorm_modulate_fp8(x_i, xn8_i, ws.xs_i, ch(mi, 3), ch(mi, 4))
         ops.layernorm_modulate_fp8(x_t, xn8_t, ws.xs_t, ch(mt, 3), ch(mt, 4))
@@ -290,8 +322,15 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
         ops.layernorm_modulate(x_t, xn_t, ch(mt, 3), ch(mt, 4))
         ops.linear_grouped([P(xn_i, pl.ff1_img_w, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0),
                             P(xn_t, pl.ff1_txt_w, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0)])
-    ops.linear_grouped([P(ws.ffh[:, T:], pl.ff2_img_w, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject),
-                        P(ws.ffh[:, :T], pl.ff2_txt_w, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t)])
+    if pl.ff2_img_w8 is not None:
+        a8 = ws.fp8_wide(4 * d)
+        ops.quantize_rows_fp8_into(ws.ffh[:, T:], a8[:, T:], ws.xs_i)
+        ops.quantize_rows_fp8_into(ws.ffh[:, :T], a8[:, :T], ws.xs_t)
+        ops.linear_grouped([P(a8[:, T:], pl.ff2_img_w8, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject, a_scale=ws.xs_i, w_scale=pl.ff2_img_ws),
+                            P(a8[:, :T], pl.ff2_txt_w8, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t, a_scale=ws.xs_t, w_scale=pl.ff2_txt_ws)])
+    else:
+        ops.linear_grouped([P(ws.ffh[:, T:], pl.ff2_img_w, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject),
+                            P(ws.ffh[:, :T], pl.ff2_txt_w, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t)])
 
 
 def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: int, inject: Optional[torch.Tensor] = None,
@@ -314,7 +353,12 @@ def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
     q = big[..., 2 * d : 3 * d]
     ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)
-    ops.linear(big[..., 2 * d :], pl.out_w, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x)
+    if pl.out_w8 is not None:
+        a8 = ws.fp8_wide(5 * d)
+        ops.quantize_rows_fp8_into(big[..., 2 * d :], a8, ws.xs_all)
+        ops.linear(a8, pl.out_w8, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x, a_scale=ws.xs_all, w_scale=pl.out_ws)
+    else:
+        ops.linear(big[..., 2 * d :], pl.out_w, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x)
     if inject is not None:                                                       # A.3: image tokens only
         for b in range(ws.B):   # image rows of one batch entry are contiguous; one call per image
             ops.masked_accumulate_(ws.x[b, T:].unsqueeze(0), inject[b : b + 1].contiguous(), None, 1.0, True)

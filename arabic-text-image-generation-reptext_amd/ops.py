@@ -251,6 +251,25 @@ def quantize_rows_fp8(x: torch.Tensor):
     return q, sc
 
 
+def quantize_rows_fp8_into(x: torch.Tensor, out: torch.Tensor, scale: torch.Tensor) -> None:
+    """x [B,R,D] bf16|f32 view (unit inner stride, any row / batch stride) -> out [B,R,D] e4m3 view, scale f32 [B*R] contiguous
+    (row b*R + r): the A operand and a_scale of an fp8 LinearProblem for activations that do not come out of a LayerNorm."""
+    if x.dim() != 3 or out.dim() != 3 or x.shape != out.shape or x.stride(2) != 1 or out.stride(2) != 1:
+        raise ValueError("quantize_rows_fp8_into: x/out must be [B,R,D] views with unit inner stride")
+    B, R, D = x.shape
+    if scale.numel() != B * R or not scale.is_contiguous():
+        raise ValueError("scale must be contiguous with B*R elements")
+    if x.dtype not in (BF16, F32):
+        raise TypeError("x must be bf16 or f32")
+    lib, st = native.load(), _stream()
+    esz = x.element_size()
+    _dev(out, "out", FP8), _dev(scale, "scale", F32), _dev(x, "x")
+    for b in range(B):
+        native.check("rt_quantize_rows_fp8", lib.rt_quantize_rows_fp8(
+            x.data_ptr() + b * x.stride(0) * esz, x.stride(1), int(x.dtype == F32), out.data_ptr() + b * out.stride(0), out.stride(1),
+            scale.data_ptr() + b * R * 4, R, D, st))
+
+
 def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_txt, wk_txt, wq_img, wk_img,
                     cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6) -> None:
     """In place on buf [B,S,ld] bf16: heads at columns q_off + h*128 / k_off + h*128."""

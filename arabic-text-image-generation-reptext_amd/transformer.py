@@ -84,13 +84,16 @@ class _MMDiTBase(nn.Module, WeightsIO):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
-    def enable_fp8_linears(self, on: bool = True):
+    def enable_fp8_linears(self, on=True):
         """BASELINE config 5 ("fp8 weights"): run the projections that read a LayerNorm output — to_q/k/v, add_q/k/v_proj,
         ff.net.0, ff_context.net.0, proj_mlp (58 % of the block's GEMM FLOPs) — on the e4m3 MFMA path. Weights are quantised
         per output channel when the plans are (re)built, activations per token inside the LayerNorm kernel; everything else
         (attention, out/down projections, residual stream, adaLN) is unchanged. Accuracy: e4m3 carries 3 mantissa bits —
-        see DESIGN.md §4 for the measured floor."""
-        self._fp8_linears = bool(on)
+        see DESIGN.md §4 for the measured floor. ``on="all"`` adds to_out / to_add_out, ff.net.2 and proj_out, whose bf16 inputs
+        (attention output, GELU hidden) are quantised per token by one extra pass each."""
+        if on not in (True, False, "ln", "all"):
+            raise ValueError("enable_fp8_linears: True/'ln' (LayerNorm-fed projections), 'all' (every block projection), or False")
+        self._fp8_linears = "ln" if on is True else on
         self._plans = None
         return self
 

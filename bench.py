@@ -34,8 +34,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--inference-steps", type=int, default=28)
     ap.add_argument("--text-lines", type=int, default=1)
-    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
-                    help="bf16 = BASELINE config 2 (the headline); fp8 = config 5's 'fp8 weights': LayerNorm-fed projections on the e4m3 MFMA path")
+    ap.add_argument("--precision", choices=["bf16", "fp8-ln", "fp8"], default="bf16",
+                    help="bf16 = BASELINE config 2 (the headline); config 5's 'fp8 weights': fp8-ln = LayerNorm-fed projections on the e4m3 "
+                         "MFMA path, fp8 = every projection of the blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="DEBUG ONLY: scale layer counts (result flagged invalid)")
@@ -224,9 +225,10 @@ def main():
     tkw = {k: v for k, v in cfg_t.items()}
     transformer = FluxTransformer2DModel(**tkw, device=dev, dtype=bf16).random_init_(seed=0)
     controlnet = FluxControlNetModel(**cfg_c, device=dev, dtype=bf16).random_init_(seed=1)   # zero-linears random too
-    if args.precision == "fp8":
-        transformer.enable_fp8_linears(True)
-        controlnet.enable_fp8_linears(True)
+    if args.precision != "bf16":
+        level = "ln" if args.precision == "fp8-ln" else "all"
+        transformer.enable_fp8_linears(level)
+        controlnet.enable_fp8_linears(level)
     vae = AutoencoderKL(**flux_vae_config(), device=dev, dtype=bf16).random_init_(seed=2)
     pipe = FluxControlNetPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=None, tokenizer=None,
                                   text_encoder_2=None, tokenizer_2=None, transformer=transformer, controlnet=controlnet)
@@ -322,7 +324,8 @@ def main():
             "loop_only_ms_per_step": None if loop_ms is None else round(loop_ms, 2),          # rank 0, median over the timed passes
             "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp8-ln": "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16",
+                      "fp8": "fp8 (e4m3 block projections) + bf16 attention"}[args.precision], "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
                        "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},

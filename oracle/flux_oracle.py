@@ -47,10 +47,14 @@ _FP8_SUFFIXES = (".attn.to_q", ".attn.to_k", ".attn.to_v", ".attn.add_q_proj", "
                  ".ff.net.0.proj", ".ff_context.net.0.proj", ".proj_mlp")
 
 
+_FP8_SUFFIXES_ALL = _FP8_SUFFIXES + (".attn.to_out.0", ".attn.to_add_out", ".ff.net.2", ".ff_context.net.2", ".proj_out")
+
+
 @contextlib.contextmanager
-def fp8_linears(on: bool = True):
+def fp8_linears(on=True):
+    """on: True / "ln" = the LayerNorm-fed projections, "all" = every projection inside the blocks."""
     global _FP8
-    prev, _FP8 = _FP8, on
+    prev, _FP8 = _FP8, ("ln" if on is True else on)
     try:
         yield
     finally:
@@ -73,7 +77,7 @@ def _ln_out(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------- primitives
 def linear(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
     w = p[name + ".weight"]
-    if _FP8 and name.endswith(_FP8_SUFFIXES):
+    if _FP8 and "transformer_blocks." in name and name.endswith(_FP8_SUFFIXES_ALL if _FP8 == "all" else _FP8_SUFFIXES):
         return F.linear(quant_rows_e4m3(x), quant_rows_e4m3(w), p.get(name + ".bias"))
     return F.linear(x, w, p.get(name + ".bias"))
 

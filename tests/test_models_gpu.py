@@ -180,6 +180,15 @@ def test_fp8_linears_transformer_and_tower(gpu):
     print(f"fp8 transformer rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e}; bf16 path {rel_l2(out16, ref):.3e})")
     assert_at_dtype_floor(err, err8, floor)
     assert err < 3e-2
+    # level "all": to_out / ff.net.2 / proj_out too, their bf16 inputs quantised by a pass
+    tr.enable_fp8_linears("all")
+    out8a = call_t()
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("all"):
+        ref8a = orc.transformer_forward(*targs, guidance=x["guidance"])
+    erra, err8a, floora = rel_l2(out8a, ref), rel_l2(out8a, ref8a), rel_l2(ref8a, ref)
+    print(f"fp8-all transformer rel-L2 {erra:.3e} vs fp32 oracle, {err8a:.3e} vs fp8 oracle (floor {floora:.3e})")
+    assert_at_dtype_floor(erra, err8a, floora)
+    assert erra < 3e-2
     tr.enable_fp8_linears(False)
     assert torch.equal(call_t(), out16)                                   # and switching back restores the bf16 path bit for bit
     # tower

@@ -373,3 +373,42 @@ def test_tower_stream_overlap_is_bitwise_neutral(vae_pair, gpu, monkeypatch):
     monkeypatch.setattr(P, "OVERLAP_TOWER", True)
     for _ in range(3):
         assert torch.equal(pipe(**kw).images, serial)
+
+
+def test_pipeline_fp8_linears(vae_pair, gpu):
+    """Config-5 precision through the whole loop (C1 shape, 4 steps, masked tower): latents vs the fp32 oracle and vs the oracle
+    with the same e4m3 quantisation points; the GPU must sit on that run's floor."""
+    from PIL import Image
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tp = orc.init_mmdit_params(SMALL_T, seed=81)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=82, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    tr.enable_fp8_linears(); cn.enable_fp8_linears()
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    N, T, steps = 256, 64, 4
+    g = torch.Generator().manual_seed(15)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    pe, pooled, hint = r(1, T, 256), r(1, 64), r(1, N, 128)
+    lat0 = orc.pack_latents(r(1, 16, 32, 32))
+    mask_np = np.zeros([256, 256], dtype=np.uint8); mask_np[60:140, 80:200] = 255
+    rm = torch.nn.functional.interpolate(torch.from_numpy(mask_np)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1)
+    sig = orc.flow_sigmas(steps, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    args = (tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, [hint], [rm], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
+    ref = orc.denoise_loop(*args)
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears():
+        ref8 = orc.denoise_loop(*args)
+    b16 = lambda t: t.to(gpu, torch.bfloat16)
+    out = pipe(prompt_embeds=b16(pe), pooled_prompt_embeds=b16(pooled), height=256, width=256, num_inference_steps=steps, guidance_scale=3.5,
+               control_image=[b16(hint)], control_mask=[Image.fromarray(mask_np)], latents=b16(lat0), output_type="latent").images.float().cpu()
+    err, err8, floor = rel_l2(out, ref), rel_l2(out, ref8), rel_l2(ref8, ref)
+    print(f"fp8-linears pipeline latents rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e})")
+    assert_at_dtype_floor(err, err8, floor)
+    assert err < 1e-2
