@@ -60,6 +60,9 @@ SIGNATURES = {
     "rt_layernorm_modulate": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_qk_rmsnorm_rope": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
+    "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "rt_attention_fp8_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_euler_step": [_vp, _vp, _f32, _i64, _vp],
     "rt_euler_step_f32": [_vp, _vp, _vp, _f32, _i64, _vp],
     "rt_cfg_mix": [_vp, _vp, _vp, _f32, _i64, _vp],
@@ -84,7 +87,7 @@ SIGNATURES.update({
 })
 
 # entries that do not return a status code
-RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64}
+RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64, "rt_attention_fp8_vt_bytes": C.c_int64}
 
 _lib = None
 

@@ -298,6 +298,35 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+def attention_fp8_prep(buf: torch.Tensor, q_off: int, k_off: int, v_off: int, H: int, T: int, wq_txt, wk_txt, wq_img, wk_img,
+                       cos: torch.Tensor, sin: torch.Tensor, qk8: torch.Tensor, vt8: torch.Tensor, eps: float = 1e-6) -> None:
+    """From the fused projection buffer buf [B,S,ld] bf16 (not modified): qk8 [B,S,2·H·128] e4m3 = 16 · RoPE(RMSNorm(q | k)),
+    vt8 flat e4m3 of rt_attention_fp8_vt_bytes(B,S,H) bytes = Vᵀ per (batch, head), keys in MFMA operand order."""
+    if buf.dim() != 3 or buf.stride(2) != 1:
+        raise ValueError("buf must be [B,S,ld] with unit inner stride")
+    B, S, _ = buf.shape
+    if cos.shape != (S, 128) or sin.shape != (S, 128) or not cos.is_contiguous() or not sin.is_contiguous():
+        raise ValueError("cos/sin must be contiguous [S,128]")
+    lib = native.load()
+    if qk8.shape != (B, S, 2 * H * 128) or not qk8.is_contiguous() or vt8.numel() < int(lib.rt_attention_fp8_vt_bytes(B, S, H)):
+        raise ValueError("qk8 must be contiguous [B,S,2*H*128]; vt8 must hold rt_attention_fp8_vt_bytes(B,S,H) bytes")
+    native.check("rt_attention_fp8_prep", lib.rt_attention_fp8_prep(
+        _dev(buf, "buf", BF16), buf.stride(1), buf.stride(0), q_off, k_off, v_off, _opt(wq_txt, "wq_txt", BF16), _opt(wk_txt, "wk_txt", BF16),
+        _dev(wq_img, "wq_img", BF16), _dev(wk_img, "wk_img", BF16), _dev(cos, "cos", F32), _dev(sin, "sin", F32),
+        _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), B, S, T, H, float(eps), _stream()))
+
+
+def attention_fp8(qk8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q kᵀ · scale) v from attention_fp8_prep's buffers -> out [B,S,>=H*128] bf16 view (unit inner stride)."""
+    B, S, _ = qk8.shape
+    if out.dim() != 3 or out.shape[0] != B or out.shape[1] != S or out.stride(2) != 1:
+        raise ValueError("out must be [B,S,*] with unit inner stride")
+    native.check("rt_attention_fp8_fwd", native.load().rt_attention_fp8_fwd(
+        _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), _dev(out, "out", BF16), out.stride(1), out.stride(0), B, S, H,
+        float(scale if scale is not None else 128 ** -0.5), _stream()))
+    return out
+
+
 def euler_step_(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> torch.Tensor:
     if not (x.is_contiguous() and v.is_contiguous()) or x.shape != v.shape:
         raise ValueError("euler_step_: contiguous tensors of equal shape")

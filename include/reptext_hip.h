@@ -140,6 +140,21 @@ int rt_attention_fwd(const void* q, const void* k, const void* v, void* o,
                      int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
                      int32_t B, int32_t S, int32_t H, float scale, void* stream);
 
+/* BASELINE config 5, "CDNA4 fp8 MFMA attention": the same joint attention with e4m3 q, k, v and softmax numerators on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 scores, statistics and accumulators; bf16 output). Static quantisation: q and k
+ * (RMS-normalised) are stored as e4m3(16·x), v is cast as is, no calibration pass.
+ * rt_attention_fp8_prep replaces rt_qk_rmsnorm_rope on this path: from the fused projection buffer (row (b,s): q at q_off,
+ * k at k_off, v at v_off, H heads of 128) it writes qk8 = [B][S][2·H·128] bytes (normalised, rotated q | k) and
+ * vt8 = [B][H][128][S64] bytes (S64 = S rounded up to 64; Vᵀ with the keys of every 64-key tile permuted into MFMA operand
+ * order, zero beyond S); rt_attention_fp8_vt_bytes gives vt8's size. buf is not modified. */
+int64_t rt_attention_fp8_vt_bytes(int32_t B, int32_t S, int32_t H);
+int rt_attention_fp8_prep(const void* buf, int64_t ld, int64_t stride_b, int64_t q_off, int64_t k_off, int64_t v_off,
+                          const void* wq_txt, const void* wk_txt, const void* wq_img, const void* wk_img,
+                          const float* cosv, const float* sinv, void* qk8, void* vt8,
+                          int32_t B, int32_t S, int32_t T, int32_t H, float eps, void* stream);
+int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, int64_t ldo, int64_t stride_ob,
+                         int32_t B, int32_t S, int32_t H, float scale, void* stream);
+
 /* FlowMatchEulerDiscreteScheduler.step (PIPE:1109; A.6): x = bf16(f32(x) + dsigma·f32(v)), in place. */
 int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream);
 

@@ -141,10 +141,34 @@ def time_text_embed(p: Params, prefix: str, t1000: torch.Tensor, g1000: Optional
     return temb + mlp("text_embedder", pooled)
 
 
+_FP8_ATTN = False
+
+
+@contextlib.contextmanager
+def fp8_attention(on: bool = True):
+    """Emulate csrc/attention_fp8.hip's static quantisation: q, k -> e4m3(16·x) (the 1/256 goes into the scale), v -> e4m3(v),
+    numerators -> e4m3(exp2(s - max + 2)); row sums from the unrounded numerators; fp32 everywhere else."""
+    global _FP8_ATTN
+    prev, _FP8_ATTN = _FP8_ATTN, on
+    try:
+        yield
+    finally:
+        _FP8_ATTN = prev
+
+
+def _e4m3(x: torch.Tensor) -> torch.Tensor:
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """softmax(q k^T / sqrt(Dh)) v, inputs [B,S,H,Dh] -> [B,S,H*Dh] (A.1 step 6)."""
     B, S, H, Dh = q.shape
     qh, kh, vh = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    if _FP8_ATTN:
+        s = (_e4m3(qh * 16.0) @ _e4m3(kh * 16.0).transpose(-1, -2)) * (1.0 / (256.0 * math.sqrt(Dh)))
+        e = torch.exp2((s - s.amax(dim=-1, keepdim=True)) * math.log2(math.e) + 2.0)
+        o = (_e4m3(e) @ _e4m3(vh)) / e.sum(dim=-1, keepdim=True)
+        return _s(o.permute(0, 2, 1, 3).reshape(B, S, H * Dh))
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(Dh)
     if _STORE is None:
         o = torch.softmax(s, dim=-1) @ vh

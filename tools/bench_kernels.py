@@ -71,6 +71,22 @@ def bench_attn():
         print(f"attn B={B} S={S} H={H}: {t*1e6:9.1f} us  {4*B*H*S*S*128/t/1e12:8.1f} TF/s", flush=True)
 
 
+def bench_attn_fp8():
+    from reptext_amd import native
+    FP8 = torch.float8_e4m3fn
+    for B, S, H in [(1, 4608, 24), (1, 9728, 24)]:
+        d = H * 128
+        qkv = torch.randn(B, S, 3 * d, device=dev).to(torch.bfloat16)
+        w = torch.ones(128, device=dev, dtype=torch.bfloat16)
+        cos = torch.ones(S, 128, device=dev); sin = torch.zeros(S, 128, device=dev)
+        qk8 = torch.empty(B, S, 2 * d, device=dev, dtype=FP8)
+        vt8 = torch.empty(int(native.load().rt_attention_fp8_vt_bytes(B, S, H)), device=dev, dtype=FP8)
+        out = torch.empty(B, S, d, device=dev, dtype=torch.bfloat16)
+        tp = timeit(lambda: ops.attention_fp8_prep(qkv, 0, d, 2 * d, H, 512, w, w, w, w, cos, sin, qk8, vt8))
+        t = timeit(lambda: ops.attention_fp8(qk8, vt8, out, H))
+        print(f"attn fp8 B={B} S={S} H={H}: prep {tp*1e6:7.1f} us, kernel {t*1e6:9.1f} us  {4*B*H*S*S*128/t/1e12:8.1f} TF/s", flush=True)
+
+
 def bench_elem():
     S, d = 4608, 3072
     x = torch.randn(1, S, d, device=dev).to(torch.bfloat16)
@@ -98,5 +114,7 @@ if __name__ == "__main__":
         bench_gemm_fp8()
     if what in ("attn", "all"):
         bench_attn()
+    if what in ("attn8", "all"):
+        bench_attn_fp8()
     if what in ("elem", "all"):
         bench_elem()
