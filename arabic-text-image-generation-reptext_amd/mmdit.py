@@ -76,6 +76,7 @@ class DoublePlan:
     ff2_img_ws: Optional[torch.Tensor] = None
     ff2_txt_w8: Optional[torch.Tensor] = None
     ff2_txt_ws: Optional[torch.Tensor] = None
+    fp8_attention: bool = False
 
 
 @dataclass
@@ -92,6 +93,7 @@ class SinglePlan:
     fused_ws: Optional[torch.Tensor] = None
     out_w8: Optional[torch.Tensor] = None
     out_ws: Optional[torch.Tensor] = None
+    fp8_attention: bool = False
 
 
 def _fuse(lins) -> tuple:
@@ -108,7 +110,7 @@ def _fuse(lins) -> tuple:
     return w, b
 
 
-def plan_double(blk, fp8=False) -> DoublePlan:
+def plan_double(blk, fp8=False, fp8_attention: bool = False) -> DoublePlan:
     """fp8: False | 'ln' (LayerNorm-fed projections) | 'all' (every projection of the block)."""
     a = blk.attn
     qi_w, qi_b = _fuse([a.to_q, a.to_k, a.to_v])
@@ -130,10 +132,11 @@ def plan_double(blk, fp8=False) -> DoublePlan:
         pl.out_txt_w8, pl.out_txt_ws = ops.quantize_rows_fp8(pl.out_txt_w)
         pl.ff2_img_w8, pl.ff2_img_ws = ops.quantize_rows_fp8(pl.ff2_img_w)
         pl.ff2_txt_w8, pl.ff2_txt_ws = ops.quantize_rows_fp8(pl.ff2_txt_w)
+    pl.fp8_attention = fp8_attention
     return pl
 
 
-def plan_single(blk, fp8=False) -> SinglePlan:
+def plan_single(blk, fp8=False, fp8_attention: bool = False) -> SinglePlan:
     a = blk.attn
     fw, fb = _fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])
     pl = SinglePlan(blk.norm.linear.weight.data, blk.norm.linear.bias.data, fw, fb, a.norm_q.weight.data,
@@ -142,6 +145,7 @@ def plan_single(blk, fp8=False) -> SinglePlan:
         pl.fused_w8, pl.fused_ws = ops.quantize_rows_fp8(pl.fused_w)
     if fp8 == "all":
         pl.out_w8, pl.out_ws = ops.quantize_rows_fp8(pl.out_w)
+    pl.fp8_attention = fp8_attention
     return pl
 
 
@@ -173,6 +177,13 @@ class Workspace:
             self.xs_i = torch.empty(B * N, device=self._device, dtype=F32)
             self.xs_all = torch.empty(B * S, device=self._device, dtype=F32)
         return self.xn8
+
+    def fp8_attn_buffers(self, H: int):
+        """(qk8 [B,S,2·H·128], vt8 flat) of rt_attention_fp8_prep."""
+        if getattr(self, "_qk8", None) is None:
+            self._qk8 = torch.empty(self.B, self.S, 2 * H * 128, device=self._device, dtype=ops.FP8)
+            self._vt8 = torch.empty(int(native.load().rt_attention_fp8_vt_bytes(self.B, self.S, H)), device=self._device, dtype=ops.FP8)
+        return self._qk8, self._vt8
 
     def fp8_wide(self, width: int) -> torch.Tensor:
         """e4m3 staging for quantised bf16 activations: [B,S,width] view of one buffer sized for the widest use (5d)."""
@@ -297,11 +308,16 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
         ops.layernorm_modulate(x_i, xn_i, ch(mi, 0), ch(mi, 1))
         ops.layernorm_modulate(x_t, xn_t, ch(mt, 0), ch(mt, 1))
         ops.linear_grouped([P(xn_i, pl.qkv_img_w, ws.qkv[:, T:], bias=pl.qkv_img_b), P(xn_t, pl.qkv_txt_w, ws.qkv[:, :T], bias=pl.qkv_txt_b)])
-    # 4.-5. RMSNorm(q,k) + RoPE in place
-    ops.qk_rmsnorm_rope(ws.qkv, 0, d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin)
-    # 6. joint attention; output over q
     q, k, v = ws.qkv[..., :d], ws.qkv[..., d : 2 * d], ws.qkv[..., 2 * d :]
-    ops.attention(q, k, v, q, H)
+    if pl.fp8_attention:
+        # 4.-6. RMSNorm(q,k) + RoPE -> e4m3 q|k and permuted Vᵀ, e4m3 joint attention; output over q
+        qk8, vt8 = ws.fp8_attn_buffers(H)
+        ops.attention_fp8_prep(ws.qkv, 0, d, 2 * d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin, qk8, vt8)
+        ops.attention_fp8(qk8, vt8, q, H)
+    else:
+        # 4.-5. RMSNorm(q,k) + RoPE in place; 6. joint attention; output over q
+        ops.qk_rmsnorm_rope(ws.qkv, 0, d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin)
+        ops.attention(q, k, v, q, H)
     # 7./8. x += gate_msa * out_proj(attn)
     if pl.out_img_w8 is not None:
         a8 = ws.fp8_wide(d)
@@ -350,9 +366,14 @@ def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     else:
         ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
         ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)    # [k|v|q|gelu(mlp)]
-    ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
     q = big[..., 2 * d : 3 * d]
-    ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)
+    if pl.fp8_attention:
+        qk8, vt8 = ws.fp8_attn_buffers(H)
+        ops.attention_fp8_prep(big, 2 * d, 0, d, H, 0, None, None, pl.nq, pl.nk, cos, sin, qk8, vt8)
+        ops.attention_fp8(qk8, vt8, q, H)
+    else:
+        ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
+        ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)
     if pl.out_w8 is not None:
         a8 = ws.fp8_wide(5 * d)
         ops.quantize_rows_fp8_into(big[..., 2 * d :], a8, ws.xs_all)

@@ -74,8 +74,8 @@ class _MMDiTBase(nn.Module, WeightsIO):
             raise TypeError(f"{type(self).__name__}: HIP path computes in bf16 storage; got {self.dtype}. Use torch_dtype=torch.bfloat16.")
         if not self.x_embedder.weight.is_cuda:
             raise RuntimeError(f"{type(self).__name__} is on {self.device}; move it to the GPU (.to('cuda')). There is no CPU fallback.")
-        fp8 = getattr(self, "_fp8_linears", False)
-        self._plans = ([mmdit.plan_double(b, fp8) for b in self.transformer_blocks], [mmdit.plan_single(b, fp8) for b in self.single_transformer_blocks])
+        fp8, fa = getattr(self, "_fp8_linears", False), getattr(self, "_fp8_attention", False)
+        self._plans = ([mmdit.plan_double(b, fp8, fa) for b in self.transformer_blocks], [mmdit.plan_single(b, fp8, fa) for b in self.single_transformer_blocks])
         self._plan_key = key
         self._rope_cache = {}
         return self._plans
@@ -83,6 +83,13 @@ class _MMDiTBase(nn.Module, WeightsIO):
     def _apply(self, fn, *a, **k):
         self._plans = None
         return super()._apply(fn, *a, **k)
+
+    def enable_fp8_attention(self, on: bool = True):
+        """BASELINE config 5 ("CDNA4 fp8 MFMA attention"): joint attention with e4m3 q, k, v and softmax numerators
+        (rt_attention_fp8_prep / rt_attention_fp8_fwd; static quantisation, see csrc/attention_fp8.hip)."""
+        self._fp8_attention = bool(on)
+        self._plans = None
+        return self
 
     def enable_fp8_linears(self, on=True):
         """BASELINE config 5 ("fp8 weights"): run the projections that read a LayerNorm output — to_q/k/v, add_q/k/v_proj,

@@ -229,6 +229,9 @@ def main():
         level = "ln" if args.precision == "fp8-ln" else "all"
         transformer.enable_fp8_linears(level)
         controlnet.enable_fp8_linears(level)
+        if args.precision == "fp8":
+            transformer.enable_fp8_attention(True)
+            controlnet.enable_fp8_attention(True)
     vae = AutoencoderKL(**flux_vae_config(), device=dev, dtype=bf16).random_init_(seed=2)
     pipe = FluxControlNetPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=None, tokenizer=None,
                                   text_encoder_2=None, tokenizer_2=None, transformer=transformer, controlnet=controlnet)
@@ -325,7 +328,7 @@ def main():
             "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8-ln": "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16",
-                      "fp8": "fp8 (e4m3 block projections) + bf16 attention"}[args.precision], "data": "synthetic",
+                      "fp8": "fp8 (e4m3 block projections and attention; bf16 storage, fp32 residual stream)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
                        "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},

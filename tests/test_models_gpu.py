@@ -201,3 +201,25 @@ def test_fp8_linears_transformer_and_tower(gpu):
         rb8, rs8 = orc.controlnet_forward(*cargs, guidance=x["guidance"])
     for a, b, b8 in zip(bs + ss, rb + rs, rb8 + rs8):
         assert_at_dtype_floor(rel_l2(a.float().cpu(), b), rel_l2(a.float().cpu(), b8), rel_l2(b8, b))
+
+
+def test_fp8_attention_in_model(gpu):
+    """Config 5 complete: e4m3 projections ('all') + e4m3 attention in both stacks, against the oracle with the same switches."""
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    tp = orc.init_mmdit_params(SMALL_T, seed=91)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp)
+    tr.enable_fp8_linears("all").enable_fp8_attention(True)
+    x = make_inputs(2, 64, 16, 24, seed=17)
+    d = to_dev(x, gpu)
+    out = tr(hidden_states=d["latents"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["timestep"],
+             img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0].float().cpu()
+    targs = (tp, SMALL_T, x["latents"], x["prompt"], x["pooled"], x["timestep"], x["img_ids"], x["txt_ids"])
+    ref = orc.transformer_forward(*targs, guidance=x["guidance"])
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("all"), orc.fp8_attention():
+        ref8 = orc.transformer_forward(*targs, guidance=x["guidance"])
+    err, err8, floor = rel_l2(out, ref), rel_l2(out, ref8), rel_l2(ref8, ref)
+    print(f"fp8 linears+attention transformer rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e})")
+    assert_at_dtype_floor(err, err8, floor)
+    assert err < 3e-2
