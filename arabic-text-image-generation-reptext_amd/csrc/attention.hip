@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     constexpr bool TAIL = decltype(tail_c)::value;
     constexpr bool RAGGED = TAIL;
     constexpr int SB = SLOT * 2 * TILE_B;
-    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); the other slot is free
+    rt_dma_barrier();                          // tile t landed (every wave's vmcnt(0), then the barrier); the other slot is free
     if constexpr (!TAIL) stage(SLOT ^ 1, (t + 1) * BKV, false);
     else if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * BKV, (t + 2) * BKV > S);
 
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_pipe_kernel(
     f32x16 (&nxt)[2] = sc[PAR ^ 1];
     const bool has_next = TAIL ? (t + 1 < ntiles) : true;
 
-    __syncthreads();     // K(t+1), V(t) landed (own vmcnt(0) + barrier); K slot PAR and V slot PAR^1 are free
+    rt_dma_barrier();    // K(t+1), V(t) landed (every wave's vmcnt(0), then the barrier); K slot PAR and V slot PAR^1 are free
     if constexpr (!TAIL) {
       stage_one(rsrcK, PAR * K_SLOT_B, t + 2, false);
       stage_one(rsrcV, V_BASE_B + (PAR ^ 1) * TILE_B, t + 1, false);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_pipe_kernel(
   stage_one(rsrcK, 0, 0, BKV > S);
   stage_one(rsrcV, V_BASE_B, 0, BKV > S);
   if (ntiles > 1) stage_one(rsrcK, K_SLOT_B, 1, 2 * BKV > S);
-  __syncthreads();
+  rt_dma_barrier();
   {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {

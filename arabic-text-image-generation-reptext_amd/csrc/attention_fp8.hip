@@ -226,7 +226,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr bool TAIL = decltype(tail_c)::value;      // last <= 3 tiles: guarded / clamped staging, masked keys
     constexpr int SB = SLOT * SLOT_B;
-    __syncthreads();
+    rt_dma_barrier();                          // tile t landed in every wave's rows; the other slot is free
     if constexpr (!TAIL) stage(SLOT ^ 1, t + 1, false);
     else if (t + 1 < ntiles) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
 

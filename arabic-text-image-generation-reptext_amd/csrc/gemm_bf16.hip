@@ -212,7 +212,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_simple_kernel(const Laun
 
   const int nk = g.K / BK;
   stage(0, 0);
-  __syncthreads();
+  rt_dma_barrier();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_simple_kernel(const Laun
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and orders buffer reuse
+    rt_dma_barrier();  // drains every wave's LDS-DMA (vmcnt(0)), then orders buffer reuse
   }
 
   // ---- epilogue: lane owns row m = ... + l15 and columns n = ... + 4*(lane>>4) .. +3 of each fragment

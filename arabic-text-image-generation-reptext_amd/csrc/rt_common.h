@@ -56,3 +56,13 @@ static inline int rt_hip_status() {
   return e == hipSuccess ? RT_OK : (int)e;
 }
 #define RT_ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
+
+// Barrier that PUBLISHES LDS-DMA data: every wave first drains its own global->LDS copies (s_waitcnt vmcnt(0)), then the
+// workgroup meets. __syncthreads() alone is not enough: its workgroup-scope fence does not wait on vector-memory operations,
+// and the compiler's own vmcnt wait is only placed before THIS wave's next LDS read (it was found missing on a loop
+// back-edge of the e4m3 attention kernel — other waves' rows were then read before they had landed, visibly so on a cold
+// first launch). Use this at every barrier after which DMA-staged rows of OTHER waves are read.
+__device__ __forceinline__ void rt_dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
   const bool wave_live = (n0 + wn * 64) < a.Cout;
   const int nk = K / BK;
   stage(0, 0);
-  __syncthreads();
+  rt_dma_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
+    rt_dma_barrier();     // next tile landed in every wave's rows; this tile's reads are done
   }
 
   if (!wave_live) return;

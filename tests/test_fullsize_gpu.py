@@ -43,6 +43,15 @@ def test_real_width_blocks_vs_oracle(gpu):
     err = rel_l2(out.float().cpu(), ref)
     print(f"real-width (d=3072, H=24) 1+1 block transformer rel-L2 {err:.3e}")
     assert err < 2e-2
+    # config-5 precision at the real width (K = 3072 / 12288 / 15360 quantised rows, 24 heads of e4m3 attention)
+    tr.enable_fp8_linears("all").enable_fp8_attention(True)
+    out8 = tr(hidden_states=b16(lat), encoder_hidden_states=b16(pe), pooled_projections=b16(pooled), timestep=ts.to(gpu), img_ids=b16(ids),
+              txt_ids=b16(tids), guidance=gd.to(gpu), return_dict=False)[0].float().cpu()
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("all"), orc.fp8_attention():
+        ref8 = orc.transformer_forward(tp, WIDE, lat, pe, pooled, ts, ids, tids, guidance=gd)
+    e, e8, floor = rel_l2(out8, ref), rel_l2(out8, ref8), rel_l2(ref8, ref)
+    print(f"real-width e4m3 projections + attention rel-L2 {e:.3e} vs fp32 oracle, {e8:.3e} vs e4m3 oracle (floor {floor:.3e})")
+    assert e <= 1.25 * floor + 1e-4 and e8 <= 1.45 * floor + 1e-4
 
 
 def test_linear_properties_at_c2_shapes(gpu):
@@ -70,6 +79,57 @@ def test_linear_properties_at_c2_shapes(gpu):
     rows = torch.randint(0, M, (64,), device=gpu, generator=g)
     ref = torch.nn.functional.linear(a[rows].float(), w[:3072].float())
     assert rel_l2(o1[rows], ref) < 2e-5
+
+
+def test_fp8_kernels_at_c2_shapes(gpu):
+    """Size-independent properties of the e4m3 kernels at the full C2 shapes: bit-exact row-permutation equivariance of the GEMM
+    (a row's result depends on that row only), exact power-of-two scaling through the row scales, bitwise repeatability of
+    GEMM and attention, and the de-quantised row-quantiser output within e4m3's half-ulp of its input."""
+    import reptext_amd.ops as ops
+    from reptext_amd import native
+
+    FP8 = torch.float8_e4m3fn
+    M, N, K = 4608, 21504, 3072
+    g = torch.Generator(device=gpu).manual_seed(0)
+    x = torch.randn(M, K, device=gpu, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=gpu, generator=g) * 0.02).to(torch.bfloat16)
+    a8 = torch.empty(1, M, K, device=gpu, dtype=FP8)
+    sa = torch.empty(M, device=gpu)
+    ops.quantize_rows_fp8_into(x[None], a8, sa)
+    deq = a8[0].float() * sa[:, None]
+    assert float(((deq - x.float()).abs() / (sa[:, None] * 448)).max()) <= 2.0 ** -4 + 1e-6      # half an ulp of the top binade
+    w8, sw = ops.quantize_rows_fp8(w)
+    out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.linear(a8[0], w8, out, a_scale=sa, w_scale=sw, gelu_from=3 * 3072)
+    perm = torch.randperm(M, device=gpu, generator=g)
+    out_p = torch.empty_like(out)
+    ops.linear(a8[0][perm].contiguous(), w8, out_p, a_scale=sa[perm].contiguous(), w_scale=sw, gelu_from=3 * 3072)
+    assert torch.equal(out_p, out[perm])
+    o1 = torch.empty(M, 3072, device=gpu, dtype=torch.float32)
+    o2 = torch.empty_like(o1)
+    ops.linear(a8[0], w8[:3072].contiguous(), o1, a_scale=sa, w_scale=sw[:3072].contiguous())
+    ops.linear(a8[0], w8[:3072].contiguous(), o2, a_scale=(sa * 4).contiguous(), w_scale=sw[:3072].contiguous())
+    assert torch.equal(o2, o1 * 4)
+    rows = torch.randint(0, M, (64,), device=gpu, generator=g)
+    ref = torch.nn.functional.linear(deq[rows], w8[:3072].float() * sw[:3072, None])
+    assert rel_l2(o1[rows], ref) < 2e-5
+    # attention at S = 4608, H = 24: repeatable bit for bit, and constant v rows come back unchanged
+    B, S, H = 1, 4608, 24
+    d = H * 128
+    qkv = torch.randn(B, S, 3 * d, device=gpu, generator=g).to(torch.bfloat16)
+    vconst = torch.randn(d, device=gpu, generator=g).to(FP8).to(torch.bfloat16)              # e4m3-exact values
+    qkv[..., 2 * d:] = vconst
+    wn = torch.ones(128, device=gpu, dtype=torch.bfloat16)
+    cos, sin = torch.ones(S, 128, device=gpu), torch.zeros(S, 128, device=gpu)
+    qk8 = torch.empty(B, S, 2 * d, device=gpu, dtype=FP8)
+    vt8 = torch.empty(int(native.load().rt_attention_fp8_vt_bytes(B, S, H)), device=gpu, dtype=FP8)
+    ops.attention_fp8_prep(qkv, 0, d, 2 * d, H, 512, wn, wn, wn, wn, cos, sin, qk8, vt8)
+    o_a = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
+    o_b = torch.empty_like(o_a)
+    ops.attention_fp8(qk8, vt8, o_a, H)
+    ops.attention_fp8(qk8, vt8, o_b, H)
+    assert torch.equal(o_a, o_b)
+    assert rel_l2(o_a.float(), vconst.float().expand(B, S, d)) < 3e-3                        # softmax weights sum to one
 
 
 def test_attention_properties_at_c2_shape(gpu):

@@ -1,0 +1,34 @@
+"""Debug aid: bitwise repeatability of rt_attention_fp8_fwd; where do differing elements sit?"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import reptext_amd.ops as ops
+from reptext_amd import native
+gpu = torch.device("cuda:0"); FP8 = torch.float8_e4m3fn
+for B, S, H in [(1, 256, 2), (1, 1024, 4), (1, 4608, 4), (1, 4608, 24), (1, 4600, 24)]:
+    d = H * 128
+    g = torch.Generator(device=gpu).manual_seed(0)
+    qkv = torch.randn(B, S, 3 * d, device=gpu, generator=g).to(torch.bfloat16)
+    wn = torch.ones(128, device=gpu, dtype=torch.bfloat16)
+    cos, sin = torch.ones(S, 128, device=gpu), torch.zeros(S, 128, device=gpu)
+    qk8 = torch.empty(B, S, 2 * d, device=gpu, dtype=FP8)
+    vt8 = torch.empty(int(native.load().rt_attention_fp8_vt_bytes(B, S, H)), device=gpu, dtype=FP8)
+    ops.attention_fp8_prep(qkv, 0, d, 2 * d, H, 0, None, None, wn, wn, cos, sin, qk8, vt8)
+    outs = []
+    for i in range(6):
+        o = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
+        ops.attention_fp8(qk8, vt8, o, H)
+        outs.append(o)
+    torch.cuda.synchronize()
+    ref = outs[0]
+    msg = []
+    for o in outs[1:]:
+        diff = (o != ref)
+        n = int(diff.sum())
+        if n:
+            rows = diff.any(dim=2)[0].nonzero().flatten()
+            cols = diff.any(dim=1)[0].nonzero().flatten()
+            msg.append(f"{n} elems; rows {rows[:6].tolist()}..({len(rows)}) row%128 {sorted(set((rows % 128).tolist()))[:10]} heads {sorted(set((cols // 128).tolist()))[:8]} maxdiff {float((o.float()-ref.float()).abs().max()):.3e}")
+        else:
+            msg.append("same")
+    print(f"S={S} H={H}:", " | ".join(msg), flush=True)
