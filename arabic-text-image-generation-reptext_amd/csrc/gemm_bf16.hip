@@ -31,7 +31,8 @@ constexpr int LDS_BYTES = 2 * BUF_BYTES;          // double buffered: 128 KiB
 
 struct GroupDev {
   rt_gemm_group g;
-  int tiles_m, tiles_n, tile_begin, pad;
+  int tiles_m, tiles_n, tile_begin;
+  int wide_store;      // bf16 output rows are 16-byte addressable in 8-column steps (C 16-B aligned, ldc/strideC/N % 8 == 0)
 };
 struct Launch {
   GroupDev grp[RT_GEMM_MAX_GROUPS];
@@ -42,7 +43,7 @@ struct Launch {
 // the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the 4 fragment columns;
 // per-row terms (residual, add2) are fetched one row ahead of the row being finished, so no store waits on a load.
 template <bool OUT_F32, bool FP8 = false>
-__device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[8][4]) {
+__device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[8][4], bool wide = false) {
   const int rpb = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   bool nok[4];
   f32x4 bias4[4], gate4[4];
@@ -99,6 +100,7 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     if ((g.res || g.add2) && i + 1 < 8) fetch_row(i + 1);
     const int mc = min(m, g.M - 1);
     const float rs = g.rowscale ? g.rowscale[mc % rpb] * g.alpha : g.alpha;
+    u32x2 packed[4];                                   // bf16 results of the 4 fragment columns (wide-store path)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = ncol + 16 * j;
@@ -131,7 +133,31 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
           u32x2 o;
           o[0] = pack_bf16x2(v[0], v[1]);
           o[1] = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
+          if (!wide) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
+        }
+      }
+      if constexpr (!OUT_F32) {
+        packed[j][0] = pack_bf16x2(v[0], v[1]);
+        packed[j][1] = pack_bf16x2(v[2], v[3]);
+      }
+    }
+    if constexpr (!OUT_F32) {
+      // Wide store: the four 16-lane groups c of a wave hold columns 4c..4c+3 of each 16-column fragment — 8 bytes per lane,
+      // 32 stores per tile. v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another;
+      // applied to the registers of fragments (j, j+1) it leaves every lane with 8 CONSECUTIVE columns (its own 4 plus its
+      // neighbour group's): groups 0/2 take fragment j, groups 1/3 fragment j+1. Same bytes, same addresses, half the store
+      // instructions (the store tail of a tile is issue-bound).
+      if (wide) {
+        const int c = (ncol >> 2) & 3;                // this lane's 16-lane group
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          const auto x = __builtin_amdgcn_permlane16_swap(packed[jp][0], packed[jp + 1][0], false, false);
+          const auto y = __builtin_amdgcn_permlane16_swap(packed[jp][1], packed[jp + 1][1], false, false);
+          const int n8 = (ncol - 4 * c) + 16 * (jp + (c & 1)) + 8 * (c >> 1);       // first of this lane's 8 columns
+          if (m < g.M && n8 < g.N) {
+            const int64_t coff = (int64_t)bidx * g.strideC + (int64_t)m * g.ldc + n8;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + coff) = u32x4{x[0], y[0], x[1], y[1]};
+          }
         }
       }
     }
@@ -445,7 +471,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
   const int mrow = m0 + wm * 128 + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
   if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);
-  else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc, G.wide_store != 0);
 }
 
 }  // namespace
@@ -477,6 +503,8 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     L.grp[i].g = g;
     L.grp[i].tiles_m = (g.M + BM - 1) / BM;
     L.grp[i].tiles_n = (g.N + BN - 1) / BN;
+    static const bool wide_on = !(getenv("RT_GEMM_WIDE_STORE") && getenv("RT_GEMM_WIDE_STORE")[0] == '0');   // A/B switch
+    L.grp[i].wide_store = (wide_on && !g.out_f32 && RT_ALIGNED(g.C, 16) && g.ldc % 8 == 0 && g.strideC % 8 == 0 && g.N % 8 == 0) ? 1 : 0;
     L.grp[i].tile_begin = total;
     total += L.grp[i].tiles_m * L.grp[i].tiles_n * g.batch;
   }
