@@ -412,3 +412,50 @@ def test_pipeline_fp8_linears(vae_pair, gpu):
     print(f"fp8-linears pipeline latents rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e})")
     assert_at_dtype_floor(err, err8, floor)
     assert err < 1e-2
+
+
+def test_pipeline_non_square_ragged_shapes(vae_pair, gpu):
+    """320 x 192 pixels -> 20 x 12 = 240 image tokens, 40 text tokens (S = 280: nothing is a multiple of a tile), two text lines,
+    batch 2 through `num_images_per_prompt`-free batching: latents vs the fp32 oracle at the bf16 floor, image decodes."""
+    from PIL import Image
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tp = orc.init_mmdit_params(SMALL_T, seed=101)
+    cp = orc.init_mmdit_params(SMALL_CN, seed=102, controlnet=True)
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp); cn.load_state_dict(cp)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    H, W, T, B, steps = 192, 320, 40, 2, 3
+    h2, w2 = 2 * (H // 16), 2 * (W // 16)
+    N = (h2 // 2) * (w2 // 2)
+    g = torch.Generator().manual_seed(23)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    pe, pooled = r(B, T, 256), r(B, 64)
+    hints = [r(B, N, 128), r(B, N, 128)]
+    lat0 = orc.pack_latents(r(B, 16, h2, w2))
+    masks_np = []
+    for box in ((16, 96, 32, 200), (100, 180, 120, 300)):
+        m = np.zeros([H, W], dtype=np.uint8); m[box[0]:box[1], box[2]:box[3]] = 255
+        masks_np.append(m)
+    rms = [torch.nn.functional.interpolate(torch.from_numpy(m)[None, None].float() / 255.0, scale_factor=1 / 16, mode="bilinear").reshape(1, -1, 1) for m in masks_np]
+    sig = orc.flow_sigmas(steps, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    args = (tp, SMALL_T, cp, SMALL_CN, lat0, pe, pooled, hints, rms, sig, orc.latent_image_ids(h2, w2), torch.zeros(T, 3), 3.5)
+    ref = orc.denoise_loop(*args)
+    with orc.stored_as(torch.bfloat16):
+        ref16 = orc.denoise_loop(*args)
+    b16 = lambda t: t.to(gpu, torch.bfloat16)
+    kw = dict(prompt_embeds=b16(pe), pooled_prompt_embeds=b16(pooled), height=H, width=W, num_inference_steps=steps, guidance_scale=3.5,
+              control_image=[b16(h) for h in hints], control_mask=[Image.fromarray(m) for m in masks_np], latents=b16(lat0))
+    out = pipe(**kw, output_type="latent").images.float().cpu()
+    err, err16, floor = rel_l2(out, ref), rel_l2(out, ref16), rel_l2(ref16, ref)
+    print(f"non-square ragged pipeline latents rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle (floor {floor:.3e})")
+    assert_at_dtype_floor(err, err16, floor)
+    assert err < 1.5e-3
+    imgs = pipe(**kw).images
+    assert len(imgs) == B and imgs[0].size == (W, H)
