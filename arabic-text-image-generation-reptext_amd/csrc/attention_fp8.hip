@@ -315,7 +315,10 @@ __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + wave * 32 + l31;
-  if (qrow < S) {
+  const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
+  if (wide) {
+    rt_store_o_rows(O + b * stride_ob + (int64_t)min(qrow, S - 1) * ldo + head * DH, qrow < S, hh, o_acc, inv);
+  } else if (qrow < S) {
     bf16_t* op = O + b * stride_ob + (int64_t)qrow * ldo + head * DH + 4 * hh;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)

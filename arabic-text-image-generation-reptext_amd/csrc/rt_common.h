@@ -57,6 +57,27 @@ static inline int rt_hip_status() {
 }
 #define RT_ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
 
+// Row-per-lane epilogue of the attention kernels: lane (q = lane&31, hh = lane>>5) holds, per (dt, g), the four consecutive
+// output columns 32dt + 8g + 4hh .. +3 of its query row. v_permlane32_swap on the registers of groups (g, g+1) hands the lower
+// half-wave [own g | partner's g] and the upper half-wave [partner's g+1 | own g+1]: 16 contiguous bytes per lane, so the tile
+// is written with 8 dwordx4 stores per lane instead of 16 dwordx2 (same bytes, same addresses).
+__device__ __forceinline__ void rt_store_o_rows(bf16_t* orow /* row base + head*128, no hh offset */, bool valid, int hh,
+                                                const f32x16 (&o_acc)[4], float inv) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      u32x2 a, b;
+      a[0] = pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv);
+      a[1] = pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+      b[0] = pack_bf16x2(o_acc[dt][4 * g + 4] * inv, o_acc[dt][4 * g + 5] * inv);
+      b[1] = pack_bf16x2(o_acc[dt][4 * g + 6] * inv, o_acc[dt][4 * g + 7] * inv);
+      const auto x = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+      const auto y = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+      if (valid) *reinterpret_cast<u32x4*>(orow + dt * 32 + 8 * (g + hh)) = u32x4{x[0], y[0], x[1], y[1]};
+    }
+}
+
 // Barrier that PUBLISHES LDS-DMA data: every wave first drains its own global->LDS copies (s_waitcnt vmcnt(0)), then the
 // workgroup meets. __syncthreads() alone is not enough: its workgroup-scope fence does not wait on vector-memory operations,
 // and the compiler's own vmcnt wait is only placed before THIS wave's next LDS read (it was found missing on a loop
