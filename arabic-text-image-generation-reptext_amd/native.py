@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -63,6 +63,11 @@ SIGNATURES = {
     "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
     "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fp8_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_embedding_gather": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "rt_rmsnorm_rows": [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
+    "rt_softmax_rows_bias": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_gated_mul": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    "rt_quick_gelu": [_vp, _i64, _vp],
     "rt_euler_step": [_vp, _vp, _f32, _i64, _vp],
     "rt_euler_step_f32": [_vp, _vp, _vp, _f32, _i64, _vp],
     "rt_cfg_mix": [_vp, _vp, _vp, _f32, _i64, _vp],

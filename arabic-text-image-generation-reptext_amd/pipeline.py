@@ -128,7 +128,8 @@ class FluxControlNetPipeline:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet=None, torch_dtype=None, **kwargs):
         """Local-directory loader in the diffusers layout (model_index.json + one sub-folder per component; SURVEY.md
-        Appendix B). Text encoders/tokenizers load through `transformers` when their folders exist, else stay None and
+        Appendix B). When their folders exist the text encoders load into reptext_amd.text_encoders (HIP kernels) and the
+        tokenizers through `transformers`; else they stay None and
         the caller passes ``prompt_embeds``/``pooled_prompt_embeds``."""
         root = pretrained_model_name_or_path
         if not os.path.isdir(root):
@@ -147,7 +148,9 @@ class FluxControlNetPipeline:
         te = te2 = tok = tok2 = None
         try:
             if os.path.isdir(os.path.join(root, "text_encoder")):
-                from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5TokenizerFast
+                from transformers import CLIPTokenizer, T5TokenizerFast        # tokenisation is host-side string work
+
+                from .text_encoders import CLIPTextModel, T5EncoderModel     # the encoders themselves run on the HIP kernels
 
                 te = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", torch_dtype=dt)
                 tok = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer")

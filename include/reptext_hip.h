@@ -155,6 +155,27 @@ int rt_attention_fp8_prep(const void* buf, int64_t ld, int64_t stride_b, int64_t
 int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, int64_t ldo, int64_t stride_ob,
                          int32_t B, int32_t S, int32_t H, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prompt encoders (PIPE:232-347: T5-XXL encoder -> prompt_embeds [B,512,4096], CLIP-L text model ->
+ * pooled_prompt_embeds [B,768]). Once per prompt, outside the loop. Matrix work is rt_gemm_bf16; attention (head dim 64)
+ * is assembled per head from rt_gemm_bf16 / rt_softmax_rows_bias / rt_transpose_bf16 / rt_gemm_bf16.
+ * ---------------------------------------------------------------------------------------- */
+/* out[i][:] = table[clamp(ids[i])][:] — nn.Embedding lookup of bf16 rows (T5 `shared`, CLIP token_embedding). ids: device int32. */
+int rt_embedding_gather(const void* table, int64_t ld, const int32_t* ids, void* out, int64_t ldo,
+                        int32_t n, int32_t D, int32_t vocab, void* stream);
+/* T5LayerNorm: out = x * rsqrt(mean(x^2) + eps) * w, x bf16 or f32 (x_f32), w/out bf16. No mean subtraction, no bias. */
+int rt_rmsnorm_rows(const void* x, int64_t ldx, int32_t x_f32, const void* w, void* out, int64_t ldo,
+                    int32_t rows, int32_t D, float eps, void* stream);
+/* p = softmax(scale·s + bias) row-wise: s f32 [rows][lds], bias f32 [rows][ldb] or NULL (T5 relative-position bias, CLIP causal
+ * mask as -inf), p bf16 [rows][ldp] with columns cols..cols_out-1 zero-filled (K padding of the P·V GEMM). A fully masked row
+ * gives zeros. */
+int rt_softmax_rows_bias(const float* s, int64_t lds, const float* bias, int64_t ldb, void* p, int64_t ldp,
+                         int32_t rows, int32_t cols, int32_t cols_out, float scale, void* stream);
+/* T5 v1.1 gated-GELU tail: out[r][c] = x[r][c] · x[r][F+c], bf16 (one half already activated by the GEMM epilogue). */
+int rt_gated_mul(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t F, void* stream);
+/* CLIP quick_gelu in place on n bf16 values: x · sigmoid(1.702 x). */
+int rt_quick_gelu(void* x, int64_t n, void* stream);
+
 /* FlowMatchEulerDiscreteScheduler.step (PIPE:1109; A.6): x = bf16(f32(x) + dsigma·f32(v)), in place. */
 int rt_euler_step(void* x, const void* v, float dsigma, int64_t n, void* stream);
 
