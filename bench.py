@@ -82,7 +82,8 @@ class GemmTimer:
     def __init__(self, ops_mod):
         self.ops = ops_mod
         self.events, self.flops, self.fp8 = [], [], []
-        self._orig = None
+        self.att_events, self.att_flops = [], []
+        self._orig = self._orig_att = self._orig_att8 = None
 
     def __enter__(self):
         ops = self.ops
@@ -103,10 +104,38 @@ class GemmTimer:
             self.fp8.append(bool(problems[0].is_fp8))
 
         ops.linear_grouped = timed
+        # the second MFMA kernel of the path, timed the same way (reported beside the roofline of the dominant one)
+        self._orig_att, self._orig_att8 = ops.attention, ops.attention_fp8
+
+        def timed_att(q, k, v, out, H, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self._orig_att(q, k, v, out, H, *a, **kw)
+            e1.record()
+            self.att_events.append((e0, e1))
+            self.att_flops.append(4 * q.shape[0] * H * q.shape[1] * q.shape[1] * 128)
+            return r
+
+        def timed_att8(qk8, vt8, out, H, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self._orig_att8(qk8, vt8, out, H, *a, **kw)
+            e1.record()
+            self.att_events.append((e0, e1))
+            self.att_flops.append(4 * qk8.shape[0] * H * qk8.shape[1] * qk8.shape[1] * 128)
+            return r
+
+        ops.attention, ops.attention_fp8 = timed_att, timed_att8
         return self
 
     def __exit__(self, *a):
         self.ops.linear_grouped = self._orig
+        self.ops.attention, self.ops.attention_fp8 = self._orig_att, self._orig_att8
+
+    def attention_result(self):
+        torch.cuda.synchronize()
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1 in self.att_events)
+        return len(self.att_events), sum(self.att_flops), tot_ms * 1e-3
 
     def result(self, fp8=None):
         """(launches, flops, seconds) of all GEMM launches, or only the e4m3 (fp8=True) / bf16 (fp8=False) ones."""
@@ -311,6 +340,12 @@ def main():
                     "avg_launch_us": round(sec / n_launch * 1e6, 2), "avg_gflop_per_launch": round(fl / n_launch / 1e9, 2),
                     "e2e_tflops_per_gpu": round(fl_img * Bl * args.steps / elapsed / 1e12, 1),
                     "e2e_frac": round(fl_img * Bl * args.steps / elapsed / 2.5e15, 4)}
+        na, fla, seca = gt.attention_result()
+        if na:
+            pk = 2500.0 if args.precision != "fp8" else 5000.0
+            roofline["attention_kernel"] = {"kernel": "attention_fwd_kernel" if args.precision != "fp8" else "attention_fp8_kernel", "launches": na,
+                                            "avg_launch_us": round(seca / na * 1e6, 2), "achieved": round(fla / seca / 1e12, 1), "peak": pk,
+                                            "frac": round(fla / seca / (pk * 1e12), 4)}
         if args.precision != "bf16":
             nb, flb, secb = gt.result(fp8=False)
             roofline["bf16_gemm_launches"] = {"launches": nb, "achieved": round(flb / secb / 1e12, 1), "peak": 2500.0,
