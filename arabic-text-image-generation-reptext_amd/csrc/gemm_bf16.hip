@@ -370,11 +370,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
       }
     }
   }
+  // LDS-DMA by buffer_load ... lds: 4-SGPR descriptor per operand + the lane's invariant 32-bit byte offset + the K offset in an
+  // SGPR — no per-K-tile vector address arithmetic and half the address registers of the global_load form.
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, -1, 0x00020000);
   auto issue = [&](int part, int buf, int koff) {                        // koff in BYTES along the row
-    const char* base = ((part == 0 || part == 3) ? Ab : Wb) + koff;       // wave-uniform (SGPR) base + per-lane 32-bit offset
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(base + src[part][q]), LDS_PTR(smem + buf * BUF_BYTES + lds_off[part][q]), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * BUF_BYTES + lds_off[part][q]), 16,
+                                               (int)src[part][q], koff, 0, 0);
   };
 
   const int l15 = lane & 15;
