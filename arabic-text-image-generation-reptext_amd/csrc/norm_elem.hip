@@ -115,8 +115,44 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Row-wise e4m3 quantisation (weights once at load; activation rows that do not come out of a LayerNorm).
-// One wave per row; rows longer than the register budget are read twice (max pass, then convert pass).
+// One wave per row. bf16 rows of up to 64·8·NCH elements are read ONCE and held packed in registers between the max pass and
+// the convert pass (quantize_rows_fp8_reg_kernel); longer or f32 rows are read twice (quantize_rows_fp8_kernel).
 // ---------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_reg_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out,
+                                                                    int64_t ldo, float* __restrict__ scale, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  u32x4 v[NCH];
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    v[c] = u32x4{0u, 0u, 0u, 0u};
+    if (col < D) v[c] = *reinterpret_cast<const u32x4*>(x + (int64_t)row * ldx + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(v[c][i])), fabsf(bf16hi(v[c][i]))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.f / E4M3_MAX) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) scale[row] = sc;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        y[2 * i] = fminf(fmaxf(bf16lo(v[c][i]) * inv, -E4M3_MAX), E4M3_MAX);
+        y[2 * i + 1] = fminf(fmaxf(bf16hi(v[c][i]) * inv, -E4M3_MAX), E4M3_MAX);
+      }
+      *reinterpret_cast<u32x2*>(out + (int64_t)row * ldo + col) = pack_e4m3x8(y);
+    }
+  }
+}
+
 template <bool X_F32>
 __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const void* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out,
                                                                 int64_t ldo, float* __restrict__ scale, int rows, int D) {
@@ -483,8 +519,16 @@ int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, i
   if (D % 8 || D > 65536) return RT_E_SHAPE;
   if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8) return RT_E_ALIGN;
   const dim3 grid((rows + 3) / 4), block(256);
-  if (x_f32) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
-  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (D + 511) / 512;
+#define QR_LAUNCH(N) hipLaunchKernelGGL(quantize_rows_fp8_reg_kernel<N>, grid, block, 0, st, (const bf16_t*)x, ldx, (uint8_t*)out, ldo, scale, rows, D)
+  if (x_f32) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, grid, block, 0, st, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
+  else if (nch <= 6) QR_LAUNCH(6);
+  else if (nch <= 12) QR_LAUNCH(12);
+  else if (nch <= 24) QR_LAUNCH(24);
+  else if (nch <= 30) QR_LAUNCH(30);
+  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, grid, block, 0, st, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
+#undef QR_LAUNCH
   return rt_hip_status();
 }
 
