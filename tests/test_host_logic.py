@@ -188,3 +188,38 @@ def test_inpaint_dropin_signature_and_mask_processor():
     m = np.zeros((32, 32, 3), np.uint8); m[:16] = 200
     x = mp.preprocess(Image.fromarray(m), height=32, width=32)
     assert x.shape == (1, 1, 32, 32) and set(x.unique().tolist()) == {0.0, 1.0} and float(x[0, 0, 0, 0]) == 1.0
+
+
+def test_bench_work_model_matches_survey_8d():
+    """bench.py's algorithmic FLOPs per image = SURVEY.md §8d: block 24·S·d² + 4·S²·d, transformer 74.378 T, tower 8.309 T,
+    28 steps = 2.3152 PFLOP (the VAE decode's 10.47 T is timed but not counted); C5 shape 5.968 PFLOP."""
+    import bench
+    from reptext_amd.config import flux_dev_transformer_config, reptext_controlnet_config
+
+    ct, cc = flux_dev_transformer_config(), reptext_controlnet_config()
+    f = bench.flops_per_image(1024, 1024, 28, 1, ct, cc)
+    assert abs(f / 1e15 - 2.3152) < 1e-4
+    f5 = bench.flops_per_image(1536, 1536, 28, 1, ct, cc)
+    assert abs(f5 / 1e15 - 5.968) < 1e-3
+    # usable_cores never exceeds the cap the CPU baseline is sized for
+    assert 1 <= bench.usable_cores() <= 16
+
+
+def test_text_encoder_state_dict_keys_match_transformers():
+    """reptext_amd.text_encoders holds its weights under transformers' own state-dict keys (CPU, no kernels involved)."""
+    from transformers import CLIPTextConfig, T5Config
+    from transformers import CLIPTextModel as HFCLIP
+    from transformers import T5EncoderModel as HFT5
+    from reptext_amd.text_encoders import CLIPTextModel, T5EncoderModel
+
+    cfg = T5Config(vocab_size=64, d_model=128, d_kv=64, d_ff=192, num_layers=2, num_heads=2, feed_forward_proj="gated-gelu", is_encoder_decoder=False)
+    mine = T5EncoderModel(vocab_size=64, d_model=128, d_kv=64, d_ff=192, num_layers=2, num_heads=2, dtype=torch.bfloat16)
+    hf_keys = {k for k in HFT5(cfg).state_dict() if k != "encoder.embed_tokens.weight"}
+    assert set(mine.state_dict()) == hf_keys
+    c = CLIPTextConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=16)
+    mc = CLIPTextModel(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=16,
+                       dtype=torch.bfloat16)
+    hf = {k if k.startswith("text_model.") else "text_model." + k for k in HFCLIP(c).state_dict() if not k.endswith("position_ids")}
+    assert set(mc.state_dict()) == hf
+    with pytest.raises(RuntimeError):            # CPU tensors: no fallback
+        mine(torch.zeros(1, 64, dtype=torch.long))
