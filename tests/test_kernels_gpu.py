@@ -407,3 +407,23 @@ def test_attention_fp8(ops, gpu, B, S, H, T):
         err = rel_l2(out.float().cpu(), exact.expand(-1, S, -1, -1).reshape(B, S, d))
         print(f"   exact pattern '{name}': {err:.2e}")
         assert err < 3e-3, name
+
+
+def test_c_abi_from_plain_cpp_host(gpu, tmp_path):
+    """The boundary without Python or torch: tools/capi_smoke/capi_smoke.cpp links the shared library through the public header,
+    allocates with hipMalloc and checks rt_gemm_bf16 / rt_attention_fwd against scalar CPU arithmetic."""
+    import os
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "arabic-text-image-generation-reptext_amd")
+    exe = str(tmp_path / "capi_smoke")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "capi_smoke", "capi_smoke.cpp"),
+                    "-L" + pkg, "-lrt_reptext_hip", "-Wl,-rpath," + pkg, "-o", exe], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
