@@ -151,7 +151,10 @@ def pmc_traffic_bytes(kernel_key: str):
     Counters cannot be read from inside the timed process, so the value is the last profiled one; null when absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
-            return int(json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"])
+            d = json.load(f)
+        if kernel_key.startswith("fp8:"):          # the passes over `bench.py --precision fp8`
+            return int(d["fp8_run"]["kernels"][kernel_key[4:]]["hbm_bytes_per_launch_corrected"])
+        return int(d["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"])
     except Exception:
         return None
 
@@ -333,7 +336,7 @@ def main():
             peak, kname, tkey = 2500.0, "gemm_pp_kernel<bf16> (rt_gemm_bf16)", "gemm"
         else:                                    # dominant kernel of the fp8 run: the e4m3 instantiation, priced at the dense fp8 peak
             n_launch, fl, sec = gt.result(fp8=True)
-            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", None
+            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", "fp8:gemm_pp_kernel<true>"
         ach = fl / sec / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic_bytes(tkey) if tkey else None, "kernel": kname, "launches": n_launch,
