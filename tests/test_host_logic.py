@@ -223,3 +223,13 @@ def test_text_encoder_state_dict_keys_match_transformers():
     assert set(mc.state_dict()) == hf
     with pytest.raises(RuntimeError):            # CPU tensors: no fallback
         mine(torch.zeros(1, 64, dtype=torch.long))
+
+
+def test_t5_relative_position_bucket_matches_transformers_cpu():
+    """Host-side piece of the T5 encoder, pinned against the real implementation (transformers is importable here)."""
+    from transformers.models.t5.modeling_t5 import T5Attention
+    from reptext_amd.text_encoders import t5_relative_position_bucket
+
+    rel = torch.arange(-700, 700)[None, :] - torch.arange(0, 5)[:, None]
+    for nb, md in ((32, 128), (64, 256), (16, 64)):
+        assert torch.equal(t5_relative_position_bucket(rel, nb, md), T5Attention._relative_position_bucket(rel, True, nb, md))
