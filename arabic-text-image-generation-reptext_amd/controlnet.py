@@ -20,7 +20,7 @@ from . import mmdit, ops
 from .config import Config
 from .modules import Lin
 from .ops import LinearProblem as P
-from .transformer import _MMDiTBase
+from .transformer import StaticEmbeds, _MMDiTBase
 
 
 @dataclass
@@ -104,6 +104,38 @@ class FluxControlNetModel(_MMDiTBase):
         cn.zero_init_controlnet_()
         return cn
 
+    def _padded_hint(self, cond: torch.Tensor):
+        """(cond, weight) of controlnet_x_embedder with K padded to a multiple of 64 — e.g. the inpaint tower's 64 + 4 = 68
+        hint channels (INP:807-813): the MFMA K-loop steps by 64, so both operands get zero columns. The padded weight is
+        cached until the parameter is rewritten (load_state_dict / random_init_ / .to clear it)."""
+        cxw = self.controlnet_x_embedder.weight.data
+        kin = cxw.shape[1]
+        if kin % 64 == 0:
+            return cond, cxw
+        kp = (kin + 63) // 64 * 64
+        if getattr(self, "_cx_pad", None) is None or self._cx_pad.device != cxw.device:
+            wpad = torch.zeros(cxw.shape[0], kp, device=cxw.device, dtype=cxw.dtype)
+            wpad[:, :kin] = cxw
+            self._cx_pad = wpad
+        return torch.nn.functional.pad(cond, (0, kp - kin)), self._cx_pad
+
+    def _invalidate_derived(self):
+        self._cx_pad = None
+
+    def load_state_dict(self, sd, strict: bool = True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._invalidate_derived()
+        return out
+
+    def random_init_(self, *a, **k):
+        out = super().random_init_(*a, **k)
+        self._invalidate_derived()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate_derived()
+        return super()._apply(fn, *a, **k)
+
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, controlnet_cond: torch.Tensor, controlnet_mode: torch.Tensor = None,
                 conditioning_scale: float = 1.0, encoder_hidden_states: torch.Tensor = None,
@@ -112,13 +144,18 @@ class FluxControlNetModel(_MMDiTBase):
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, return_dict: bool = True,
                 _rowscale: Optional[torch.Tensor] = None, _accumulate_into: Optional[Sequence[torch.Tensor]] = None,
                 _accumulate_single_into: Optional[Sequence[torch.Tensor]] = None, _mods: Optional["mmdit.StepMods"] = None,
-                _overwrite: bool = False, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None, _ws_tag: str = ""):
+                _overwrite: bool = False, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None, _ws_tag: str = "",
+                _static: Optional[StaticEmbeds] = None, _blocks_needed: Optional[Tuple[int, int]] = None):
         """Same contract as CN:216-413. ``joint_attention_kwargs`` is accepted and ignored (LoRA scale plumbing, no
         PEFT on this path). The private ``_rowscale`` / ``_accumulate_into`` arguments let the pipeline fuse its
         regional mask (PIPE:1062) and the sum over text lines (PIPE:1076-1080) into the zero-linear epilogues; with
         ``_overwrite`` the ``_accumulate_into`` buffers are written, not added to (first text line into preallocated
         buffers). ``_sample_events[i]`` is recorded on the current stream once double-block sample i is complete and
-        ``_ws_tag`` selects a private workspace — both for running the tower on a side stream next to the transformer."""
+        ``_ws_tag`` selects a private workspace — both for running the tower on a side stream next to the transformer.
+        ``_static``: this tower's loop-invariant embeddings for (prompt, this hint) from ``prepare_static`` — the per-step work
+        is then x_embedder only. ``_blocks_needed`` = (double, single): evaluate only that many leading blocks; the samples of
+        the rest come back as None (the pipeline knows which samples the transformer consumes: with 6 samples against 19
+        blocks the sixth is never read, quirk Q5)."""
         doubles, singles = self._ensure_plans()
         cfg = self.config
         if self.union:
@@ -131,28 +168,22 @@ class FluxControlNetModel(_MMDiTBase):
         H, d = cfg.num_attention_heads, self.inner_dim
         ws = mmdit.workspace(Bc, T, N, d, hidden_states.device, need_single=len(singles) > 0, tag=_ws_tag)
         hs = hidden_states.to(torch.bfloat16)
-        cond = controlnet_cond.to(torch.bfloat16)
         if hs.shape[0] != Bc:          # Q6: latents batch B against conditioning batch 2B broadcasts (B == 1 under CFG)
             hs = hs.expand(Bc, -1, -1) if hs.shape[0] == 1 else hs.repeat(Bc // hs.shape[0], 1, 1)
-        if cond.shape[0] != Bc:
-            cond = cond.expand(Bc, -1, -1) if cond.shape[0] == 1 else cond.repeat(Bc // cond.shape[0], 1, 1)
         x_i, x_t = ws.x[:, T:], ws.x[:, :T]
         # CN:277-292: h = x_embedder(latents) + controlnet_x_embedder(cond); e = context_embedder(prompt)
-        ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, x_i, bias=self.x_embedder.bias.data),
-                            P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, x_t,
-                              bias=self.context_embedder.bias.data)])
-        cxw = self.controlnet_x_embedder.weight.data
-        kin = cxw.shape[1]
-        if kin % 64:
-            # e.g. the inpaint tower's 64 + 4 = 68 hint channels (INP:807-813): the MFMA K-loop steps by 64, so pad K with zeros
-            kp = (kin + 63) // 64 * 64
-            if getattr(self, "_cx_pad", None) is None or self._cx_pad[1] != cxw.data_ptr():
-                wpad = torch.zeros(cxw.shape[0], kp, device=cxw.device, dtype=cxw.dtype)
-                wpad[:, :kin] = cxw
-                self._cx_pad = (wpad, cxw.data_ptr())
-            cxw = self._cx_pad[0]
-            cond = torch.nn.functional.pad(cond, (0, kp - kin))
-        ops.linear(cond.contiguous(), cxw, x_i, bias=self.controlnet_x_embedder.bias.data, res=x_i)
+        if _static is not None:
+            x_t.copy_(_static.ctx)                                           # device copy of the loop-invariant text rows
+            ops.linear(hs.contiguous(), self.x_embedder.weight.data, x_i, bias=self.x_embedder.bias.data, res=_static.hint)
+        else:
+            cond = controlnet_cond.to(torch.bfloat16)
+            if cond.shape[0] != Bc:
+                cond = cond.expand(Bc, -1, -1) if cond.shape[0] == 1 else cond.repeat(Bc // cond.shape[0], 1, 1)
+            ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, x_i, bias=self.x_embedder.bias.data),
+                                P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, x_t,
+                                  bias=self.context_embedder.bias.data)])
+            cond, cxw = self._padded_hint(cond)
+            ops.linear(cond.contiguous(), cxw, x_i, bias=self.controlnet_x_embedder.bias.data, res=x_i)
         temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
 
@@ -169,14 +200,24 @@ class FluxControlNetModel(_MMDiTBase):
                 ops.linear(a, lin.weight.data, out, bias=lin.bias.data, alpha=scale, rowscale=_rowscale)
             return out
 
-        block_samples: List[torch.Tensor] = []
+        nd = len(doubles) if _blocks_needed is None else min(len(doubles), int(_blocks_needed[0]))
+        ns = len(singles) if _blocks_needed is None else min(len(singles), int(_blocks_needed[1]))
+        if ns > 0:
+            nd = len(doubles)          # the single blocks read the stream all double blocks have written
+        block_samples: List[Optional[torch.Tensor]] = []
         for i, pl in enumerate(doubles):
+            if i >= nd:
+                block_samples.append(None)
+                continue
             mmdit.run_double(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.double[i])
             block_samples.append(head(self.controlnet_blocks[i], _accumulate_into, i))
             if _sample_events is not None:
                 _sample_events[i].record(torch.cuda.current_stream())
-        single_samples: List[torch.Tensor] = []
+        single_samples: List[Optional[torch.Tensor]] = []
         for i, pl in enumerate(singles):
+            if i >= ns:
+                single_samples.append(None)
+                continue
             mmdit.run_single(pl, ws, temb, cos, sin, H, mods=None if _mods is None else _mods.single[i])
             single_samples.append(head(self.controlnet_single_blocks[i], _accumulate_single_into, i))
 

@@ -3,8 +3,8 @@
 // matrix never leaves the CU. Reference: torch SDPA as called by diffusers' FluxAttnProcessor (SURVEY.md
 // Appendix A.1 step 6 / A.2), reached from controlnet_flux.py:343-348,376-380 and PIPE:1092.
 //
-// Workgroup = 4 waves = 128 query rows of one (batch, head); wave w owns query rows 32w..32w+31 for the whole
-// key sweep. Keys/values arrive in 64-row tiles by LDS-DMA into a 2-deep ring (K 16 KiB + V 16 KiB per slot).
+// Work item = 128 query rows of one (batch, head); a workgroup = 4 waves, wave w owns query rows 32w..32w+31.
+// Keys/values arrive in 64-row tiles by LDS-DMA into a 2-deep ring (K 16 KiB + V 16 KiB per slot).
 //
 // Both products run on v_mfma_f32_32x32x16_bf16 with the QUERY index on the lane:
 //   Sᵀ[key][q]  = K · Qᵀ      A = K rows from LDS (ds_read_b128), B = Q rows held in registers
@@ -12,6 +12,27 @@
 //                             registers themselves, exponentiated and packed to bf16 (no LDS round trip)
 // so the softmax max/sum of a query row are lane-local apart from one lane<->lane+32 exchange, and the
 // per-row rescale of O is a per-lane scalar multiply.
+//
+// Schedule inside a wave (per 64-key tile, two 32-key halves h0, h1):
+//   Sᵀ(h0) | Sᵀ(h1) ∥ numerators of h0 | check h0 | Oᵀ += Vᵀ(h0)·Pᵀ(h0) ∥ numerators of h1 | check h1 | Oᵀ += Vᵀ(h1)·Pᵀ(h1)
+// The numerators of a half are computed SPECULATIVELY against the running max m_run while the matrix pipe works on the
+// next product; the row max of the half is taken beside them and checked afterwards. Only when some row's max outgrew
+// m_run by more than RESCALE_THR (rare after the first tiles) a fix-up block rescales O and l and recomputes that half's
+// numerators against the new max — so the common path has no branch between an MFMA chain and the vector work that
+// overlaps it, and every numerator that reaches an MFMA was formed against the max O is normalised with.
+//
+// Placement (speed only, never correctness): the grid is one-dimensional per batch entry. Workgroups are dealt
+// round-robin over the 8 XCDs, so blockIdx.x & 7 labels the XCD group; each group owns a CONTIGUOUS run of the
+// (head, query block) items, i.e. whole heads (3 of 24 per XCD): K/V of a head are fetched into one XCD's L2 only.
+//
+// Key-split tail: with NI items per XCD group on `spx` workgroup slots (2 per CU), the last NI mod spx items would
+// occupy a partial round of full-length workgroups (864 items on 512 slots: 1.69 rounds run as 2). Instead those
+// `rem` items × ntiles key tiles are dealt to `spx` workgroups in equal contiguous runs of tiles; a run covers the
+// tail of one item and/or the head of the next. A workgroup that covers only part of an item writes its unnormalised
+// (m, l, Oᵀ) to a workspace record (write-through stores) and takes a ticket on the item's counter; the workgroup that
+// draws the last ticket combines the item's records IN RUN ORDER (not arrival order: bitwise reproducible) and
+// stores the output. Nobody waits on anybody, so no dispatch-order assumption exists. The decomposition depends on
+// (S, H, CU count) only — every batch entry is cut identically, so results do not depend on the batch size.
 //
 // LDS image of a K or V tile: 64 rows × 256 B; 16-B chunk c of row r lives at 256·r + 16·(c ^ f(r)),
 // f(r) = ((r&3)<<2) | ((r>>2)&3): conflict-free for the row reads (K) and the transposed reads (V).
@@ -23,11 +44,21 @@
 namespace {
 
 constexpr int DH = 128;
-constexpr int BQ = 128;       // query rows per workgroup
+constexpr int BQ = 128;       // query rows per work item
 constexpr int BKV = 64;       // keys per tile
 constexpr int TILE_B = BKV * DH * 2;   // 16 KiB
 constexpr int ATT_THREADS = 256;
 constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64 between rescales
+constexpr int REC_WAVE_B = 64 * 64 * 4 + 64 * 8;   // one wave's partial: Oᵀ (64 registers × 64 lanes, fp32) + (m, l) per lane
+constexpr int REC_B = 4 * REC_WAVE_B;              // 67 584 B per (workgroup, segment)
+constexpr int CNT_ALIGN = 256;
+constexpr int SPLIT_MIN_TILES = 8;                 // do not split runs shorter than this many key tiles
+
+struct AttnGeom {
+  int S, H, nqb, ntiles, NI;   // NI = H * nqb work items per batch entry
+  int spx;                     // workgroup slots per XCD group (2 per CU)
+  int split;                   // key-split tail enabled (workspace present and it pays)
+};
 
 __device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
@@ -41,60 +72,79 @@ __device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// How the items of one XCD group are cut (identical on host and device; scalar arithmetic only).
+struct GroupCut {
+  int start, cnt;   // first item and number of items of this group
+  int nfull;        // items run by one full-length workgroup each
+  int rem;          // items whose key tiles are dealt to `spx` workgroups (0: no split)
+};
+__host__ __device__ inline GroupCut group_cut(const AttnGeom& G, int xcd) {
+  GroupCut c;
+  const int base = G.NI >> 3, extra = G.NI & 7;
+  c.cnt = base + (xcd < extra ? 1 : 0);
+  c.start = xcd * base + (xcd < extra ? xcd : extra);
+  c.nfull = c.cnt;
+  c.rem = 0;
+  if (G.split) {
+    const int nf = (c.cnt / G.spx) * G.spx, rem = c.cnt - nf;
+    // split when the partial round is less than 15/16 full and every run keeps >= SPLIT_MIN_TILES tiles
+    if (rem > 0 && rem * 16 < G.spx * 15 && (int64_t)rem * G.ntiles >= (int64_t)G.spx * SPLIT_MIN_TILES) {
+      c.nfull = nf;
+      c.rem = rem;
+    }
+  }
+  return c;
+}
+__host__ __device__ inline int group_slots(const AttnGeom& G, int xcd) {
+  const GroupCut c = group_cut(G, xcd);
+  return c.nfull + (c.rem ? G.spx : 0);
+}
+
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* O,
-    int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, int S, int H, float scale_log2) {
+    int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, float scale_log2, const AttnGeom G,
+    int* counters, char* records) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // [slot][K|V]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * BQ;
+  const int S = G.S;
+  const int ntiles = G.ntiles;
 
-  const bf16_t* Qb = Q + b * stride_b + head * DH;
-  const bf16_t* Kb = K + b * stride_b + head * DH;
-  const bf16_t* Vb = V + b * stride_b + head * DH;
-
-  // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7]
-  bf16x8 qf[8];
-  {
-    const int qrow = min(q0 + wave * 32 + l31, S - 1);
-    const bf16_t* qp = Qb + (int64_t)qrow * ld + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  // ---- which run of (item, key tile) pairs is this workgroup's? (scalar)
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, b = (int)blockIdx.y;
+  const GroupCut cut = group_cut(G, xcd);
+  int run_lo, run_hi;            // in units of key tiles, relative to the first item this workgroup touches
+  int item0;                     // that first item
+  int jpart = -1;                // index among the `spx` splitting workgroups, -1 for a full-length workgroup
+  if (slot < cut.nfull) {
+    item0 = cut.start + slot;
+    run_lo = 0;
+    run_hi = ntiles;
+  } else {
+    jpart = slot - cut.nfull;
+    if (cut.rem == 0 || jpart >= G.spx) return;
+    const unsigned U = (unsigned)cut.rem * (unsigned)ntiles;      // host checks rem * ntiles * spx < 2^31
+    const int lo = (int)((unsigned)jpart * U / (unsigned)G.spx), hi = (int)((unsigned)(jpart + 1) * U / (unsigned)G.spx);
+    const int i0 = lo / ntiles;
+    item0 = cut.start + cut.nfull + i0;
+    run_lo = lo - i0 * ntiles;
+    run_hi = hi - i0 * ntiles;   // may exceed ntiles: the run continues into item0 + 1
   }
 
-  // ---- staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V; K and V share row/chunk offsets.
+  // ---- per-lane constants that do not depend on the item
+  // staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V; K and V share row/chunk offsets.
   const int srow = lane >> 4;                 // row inside a piece
   const int spc = lane & 15;                  // physical chunk written by this lane
-  int srow_t[4];                              // row inside the tile per piece
-  uint32_t soff[4];                           // BYTE offset of (row, logical chunk) from the tile's first row: unsigned 32-bit,
-                                              // so the DMA address is (uniform 64-bit base in SGPRs) + (VGPR offset) with no
-                                              // per-tile 64-bit vector address arithmetic
+  uint32_t soff[4];                           // BYTE offset of (row, logical chunk) from the tile's first row
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    srow_t[p] = (wave * 4 + p) * 4 + srow;
-    soff[p] = ((uint32_t)srow_t[p] * (uint32_t)ld + (uint32_t)((spc ^ swz(srow_t[p])) << 3)) * 2u;
+    const int row_t = (wave * 4 + p) * 4 + srow;          // row inside the tile
+    soff[p] = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
   }
-  auto stage = [&](int slot, int kv0, bool clamp) {
-    char* kb = smem + slot * 2 * TILE_B;
-    const char* kt0 = reinterpret_cast<const char*>(Kb + (int64_t)kv0 * ld);      // wave-uniform tile bases
-    const char* vt0 = reinterpret_cast<const char*>(Vb + (int64_t)kv0 * ld);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      uint32_t off = soff[p];
-      if (clamp)   // ragged last tile: rows past the end re-read row S-1 (masked later)
-        off = ((uint32_t)(min(kv0 + srow_t[p], S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(srow_t[p])) << 3)) * 2u;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(kt0 + off), LDS_PTR(kb + (wave * 4 + p) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(vt0 + off), LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, 0, 0);
-    }
-  };
-
-  // ---- per-lane LDS read offsets (bytes inside a tile); everything that varies with (kt, ks, s, dt) statically is an
-  //      immediate, so the loop carries no address arithmetic.
   // K row read: row = 32kt + l31, chunk = 2ks + hh  ->  l31*256 + ((2ks+hh) ^ swz(l31))*16  (+ kt*8192)
-  lds_cptr kp[8];                             // 32-bit LDS addresses; slot / kt offsets are immediates at the use site
+  lds_cptr kp[8];
   {
     const int ksw = swz(l31);                 // swz depends on row & 15 only
 #pragma unroll
@@ -115,434 +165,432 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     }
   }
 
-  f32x16 o_acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;     // running max (log2 domain, may lag the true max by <= RESCALE_THR) and row sum
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-  const int ntiles = (S + BKV - 1) / BKV;
+  for (int seg = 0; seg < 2; ++seg) {
+    // ---- segment = the part of this workgroup's run that lies inside one item
+    const int item = item0 + seg;
+    const int tb = seg == 0 ? run_lo : 0;
+    const int te = seg == 0 ? min(run_hi, ntiles) : run_hi - ntiles;
+    if (te <= tb) break;
+    const int head = item / G.nqb;
+    const int q0 = (item - head * G.nqb) * BQ;
+    const bf16_t* Qb = Q + b * stride_b + head * DH;
+    const bf16_t* Kb = K + b * stride_b + head * DH;
+    const bf16_t* Vb = V + b * stride_b + head * DH;
 
-  auto tile = [&](auto slot_c, auto tail_c, int t) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    // TAIL = false: steady state — this tile and the one it stages are full, nothing is checked, the body is straight-line
-    // code (no address arithmetic, no branches but the rare rescale). TAIL = true: the last <= 3 tiles of a row — staging is
-    // guarded and clamped, keys >= S are masked.
-    constexpr bool TAIL = decltype(tail_c)::value;
-    constexpr bool RAGGED = TAIL;
-    constexpr int SB = SLOT * 2 * TILE_B;
-    rt_dma_barrier();                          // tile t landed (every wave's vmcnt(0), then the barrier); the other slot is free
-    if constexpr (!TAIL) stage(SLOT ^ 1, (t + 1) * BKV, false);
-    else if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * BKV, (t + 2) * BKV > S);
-
-    // ---- Sᵀ = K·Qᵀ : two 32-key tiles
-    f32x16 s_acc[2];
+    // LDS-DMA by buffer_load ... lds: 4-SGPR descriptor per operand + the lane's loop-invariant 32-bit byte offset + the tile's
+    // byte offset in an SGPR — no per-tile vector address arithmetic. num_records = 2^32-1: rows are clamped here, not by the
+    // range check (the host checks (S + 64) * ld * 2 < 2^31).
+    const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, -1, 0x00020000);
+    const int tile_stride_b = BKV * (int)ld * 2;
+    auto stage = [&](int sl, int tix, bool clamp) {
+      char* kb = smem + sl * 2 * TILE_B;
+      const int kv0 = tix * BKV;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 kf = *(const __attribute__((address_space(3))) bf16x8*)(kp[ks] + SB + kt * 8192);
-        s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kt], 0, 0, 0);
-      }
-    }
-    // key of s_acc[kt][r]: 64t + 32kt + (r&3) + 8(r>>2) + 4hh
-    if constexpr (RAGGED) {                    // mask keys >= S
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * BKV + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= S) s_acc[kt][r] = -INFINITY;
+      for (int p = 0; p < 4; ++p) {
+        uint32_t off = soff[p];
+        if (clamp) {   // ragged last tile: rows past the end re-read row S-1 (masked later)
+          const int row_t = (wave * 4 + p) * 4 + srow;
+          off = ((uint32_t)(min(kv0 + row_t, S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
         }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+      }
+    };
+
+    __syncthreads();                            // previous segment's LDS reads (tiles, ticket word) are done
+    stage(0, tb, (tb + 1) * BKV > S);     // first tile in flight before the Q loads are waited for
+
+    // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7]
+    bf16x8 qf[8];
+    {
+      const int qrow = min(q0 + wave * 32 + l31, S - 1);
+      const bf16_t* qp = Qb + (int64_t)qrow * ld + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
 
-    // ---- online softmax in the log2 domain; the row's other 32 keys live in lane ^ 32.
-    float mx = max3f(s_acc[0][0], s_acc[1][0], s_acc[0][1]);
-    mx = max3f(mx, s_acc[1][1], s_acc[0][2]);
+    f32x16 o_acc[4];
 #pragma unroll
-    for (int r = 3; r < 16; ++r) mx = max3f(mx, s_acc[0][r], s_acc[1][r - 1]);
-    mx = max3f(mx, s_acc[1][15], s_acc[1][14]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2;
-    // Deferred rescale: O and l are only rescaled when some row's max grew by more than RESCALE_THR (log2 units) over
-    // the max it is currently normalised with; otherwise P = exp2(s - m_run) <= 2^THR, harmless in fp32 accumulators
-    // and (being a relative format) in the bf16 P operand. The decision precedes every use of this tile's P.
-    if (__any(mx - m_run > RESCALE_THR)) {
-      asm volatile("" ::: "memory");           // keep this rare block a real branch (not if-converted into 64 multiplies)
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0 on zeroed state
-      m_run = m_new;
-      l_run *= alpha;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;     // running max (log2 domain, may lag the true max by <= RESCALE_THR) and row sum
+
+    // ---- softmax pieces (all per lane; the row's other keys live in lane ^ 32)
+    // row max of one 32-key half (this lane's 16 keys)
+    auto half_max = [&](const f32x16& s) -> float {
+      float ma = max3f(s[0], s[1], s[2]), mb = max3f(s[3], s[4], s[5]);
+      ma = max3f(ma, s[6], s[7]);
+      mb = max3f(mb, s[8], s[9]);
+      ma = max3f(ma, s[10], s[11]);
+      mb = max3f(mb, s[12], s[13]);
+      return fmaxf(max3f(ma, s[14], s[15]), mb);
+    };
+    // Deferred rescale: O and l are only rescaled when some row's max grew by more than RESCALE_THR (log2 units) over the
+    // max it is currently normalised with; otherwise P = exp2(s - m_run) <= 2^THR, harmless in fp32 accumulators and
+    // (being a relative format) in the bf16 P operand. Returns the factor O must be multiplied with (1 = nothing to do);
+    // m_run and l_run are updated here, O by the caller once every MFMA fed with old-scale numerators has been issued.
+    auto decide = [&](float mx, bool& pend) -> float {
+      // Both partial maxima of a row (lanes l and l+32) through one v_permlane32_swap: it exchanges the upper half of its first
+      // operand with the lower half of its second, so after it each lane holds its own value in one register and its
+      // partner's in the other. Inline asm: with the builtin, hipcc (ROCm 7.2) folds max(result[0], result[1]) to result[0]
+      // (the swap is emitted, the v_max is not), so each half-wave saw only one of the two maxima — found by the
+      // spiked-key test: a row whose largest score sat in lanes 32-63 was never rescaled. s_nop 1 = the two wait states
+      // a VALU write needs before v_permlane*_swap reads it.
+      unsigned xa = __builtin_bit_cast(unsigned, mx), xb = xa;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
+      const float mxr = fmaxf(__builtin_bit_cast(float, xa), __builtin_bit_cast(float, xb)) * scale_log2;
+      float alpha = 1.f;
+      pend = false;
+      if (__any(mxr - m_run > RESCALE_THR)) {
+        asm volatile("" ::: "memory");           // keep this rare block a real branch (not if-converted)
+        const float m_new = fmaxf(m_run, mxr);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0 on zeroed state
+        m_run = m_new;
+        l_run *= alpha;
+        pend = true;
+      }
+      return alpha;
+    };
+    auto rescale_o = [&](float alpha) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    };
+    // numerators of 8 keys (one k-step of Oᵀ += Vᵀ·Pᵀ): registers 8·s2 .. 8·s2+7 of a half
+    auto numer8 = [&](const f32x16& s, int s2, bf16x8& pf) {
+      float ps = 0.f;
+#ifdef ATT_ABL_NOSOFT
+      pf = __builtin_bit_cast(bf16x8, f32x4{s[8 * s2], s[8 * s2 + 1], s[8 * s2 + 2], s[8 * s2 + 3]});
+      ps = s[8 * s2 + 4];
+#else
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#ifdef ATT_ABL_NOEXP
+        const float p = __builtin_fmaf(s[8 * s2 + j], scale_log2, -m_run);
+#else
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[8 * s2 + j], scale_log2, -m_run));
+#endif
+        ps += p;
+        pf[j] = (__bf16)p;
+      }
+#endif
+      l_run += ps;
+    };
+
+#define RT_SB() __builtin_amdgcn_sched_barrier(0)
+// Opaque use+def: the value must exist HERE (keeps the optimiser from sinking a step's vector work below a later branch)
+#define RT_PIN(v) asm volatile("" : "+v"(v))
+// n groups of { 1 MFMA, nds LDS reads, nva vector/transcendental ops }
+#ifdef ATT_EXP_NOWEAVE
+#define RT_WEAVE(n, nds, nva)
+#else
+#define RT_WEAVE(n, nds, nva)                                          \
+  _Pragma("unroll") for (int w_ = 0; w_ < (n); ++w_) {                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    if ((nds) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (nds), 0); \
+    if ((nva) > 0) __builtin_amdgcn_sched_group_barrier(0x402, (nva), 0); \
+  }
+#endif
+
+    auto tile = [&](auto slot_c, int t) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      constexpr int SB = SLOT * 2 * TILE_B;
+      // wave-uniform, almost always false: the tile is the ragged last one of the row (keys >= S are masked) / the tile it
+      // stages is (its rows are clamped) / there is no next tile in this run
+      const bool ragged = (t + 1) * BKV > S;
+      auto kread = [&](int h, int ks) -> bf16x8 {
+#ifdef ATT_ABL_NOLDS
+        return qf[(ks + h) & 7];
+#endif
+        return *(const __attribute__((address_space(3))) bf16x8*)(kp[ks] + SB + h * 8192); };
+      auto vread = [&](int h, int s2, int dt) -> bf16x8 {
+#ifdef ATT_ABL_NOLDS
+        return qf[(dt + 2 * s2 + h) & 7];
+#endif
+        const s16x4 lo = tr_read(vp[0][dt] + SB + h * 8192 + s2 * 4096);
+        const s16x4 hi = tr_read(vp[1][dt] + SB + h * 8192 + s2 * 4096);
+        return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto mask_half = [&](f32x16& s, int h) {   // key of s{h}[r]: 64t + 32h + (r&3) + 8(r>>2) + 4hh
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * BKV + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hh >= S) s[r] = -INFINITY;
+      };
+      rt_dma_barrier();                          // tile t landed (every wave's vmcnt(0), then the barrier); the other slot is free
+#ifdef ATT_EXP_PRIO
+      __builtin_amdgcn_s_setprio(ATT_EXP_PRIO);
+#endif
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      bf16x8 kA[8], kB[8], vA[4], vB[4];         // operand fragments, read one step ahead of the MFMAs that use them
+      bf16x8 p00, p01, p10, p11;                 // numerators [half][k-step]
+      bool pend;
+      // ---- 1: Sᵀ(h0) = K[0:32]·Qᵀ (8 MFMAs) beside the LDS-DMA issue of tile t+1 and the first reads of h1
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kA[ks] = kread(0, ks);
+#ifndef ATT_ABL_NODMA
+      if (t + 1 < te) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], s0, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) kB[ks] = kread(1, ks);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int w_ = 0; w_ < 8; ++w_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (w_ >= 4 && w_ < 7) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      RT_SB();
+      // ---- 2: first 3 MFMAs of Sᵀ(h1) cover the retirement of Sᵀ(h0); row max of h0, decision (no numerators pending)
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[ks], qf[ks], s1, 0, 0, 0);
+#pragma unroll
+      for (int ks = 3; ks < 8; ++ks) kB[ks] = kread(1, ks);
+      if (ragged) mask_half(s0, 0);
+      float mx0 = half_max(s0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      RT_SB();
+      {
+        const float alpha = decide(mx0, pend);
+        if (pend) rescale_o(alpha);
+      }
+      RT_SB();
+      // ---- 3: rest of Sᵀ(h1) ∥ numerators of h0, k-step 0; Vᵀ fragments of (h0, k-step 0) come in
+#pragma unroll
+      for (int ks = 3; ks < 8; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[ks], qf[ks], s1, 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vA[dt] = vread(0, 0, dt);
+      numer8(s0, 0, p00);
+      RT_WEAVE(5, 2, 6)
+      RT_PIN(p00); RT_PIN(l_run);
+      RT_SB();
+      // ---- 4: Oᵀ += Vᵀ(h0, k-step 0)·p00 ∥ numerators of h0 k-step 1, row max of h1
+      // element j of lane-half hh of k-step (h, s2) is key 32h + 16s2 + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[dt], p00, o_acc[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vB[dt] = vread(0, 1, dt);
+      numer8(s0, 1, p01);
+      if (ragged) mask_half(s1, 1);
+      float mx1 = half_max(s1);
+      RT_WEAVE(4, 2, 9)
+      RT_PIN(p01); RT_PIN(l_run); RT_PIN(mx1);
+      RT_SB();
+      const float alpha1 = decide(mx1, pend);    // p01 (old scale) is still to be multiplied into O: O is rescaled after step 5
+      RT_SB();
+      // ---- 5: Oᵀ += Vᵀ(h0, k-step 1)·p01 ∥ numerators of h1 k-step 0 (against the new max)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vB[dt], p01, o_acc[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vA[dt] = vread(1, 0, dt);
+      numer8(s1, 0, p10);
+      RT_WEAVE(4, 2, 7)
+      RT_PIN(p10); RT_PIN(l_run);
+      RT_SB();
+      if (pend) rescale_o(alpha1);
+      RT_SB();
+      // ---- 6: Oᵀ += Vᵀ(h1, k-step 0)·p10 ∥ numerators of h1 k-step 1
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[dt], p10, o_acc[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vB[dt] = vread(1, 1, dt);
+      numer8(s1, 1, p11);
+      RT_WEAVE(4, 2, 7)
+      RT_PIN(p11); RT_PIN(l_run);
+      RT_SB();
+      // ---- 7: Oᵀ += Vᵀ(h1, k-step 1)·p11
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vB[dt], p11, o_acc[dt], 0, 0, 0);
+    };
+
+    // LDS slot = parity of (t - tb)
+    int t = tb;
+    for (; t + 1 < te; t += 2) {
+      tile(S0{}, t);
+      tile(S1{}, t + 1);
     }
-    float psum = 0.f;
-    bf16x8 pf[2][2];
+    if (t < te) tile(S0{}, t);
+
+    const int qrow = q0 + wave * 32 + l31;
+    const bool whole = (tb == 0 && te == ntiles);
+#ifdef ATT_ABL_NOCOMBINE
+    if (!whole) continue;
+#endif
+    if (!whole) {
+      // ---- partial: write (Oᵀ, m, l) of this run through to memory, take a ticket, last ticket combines the item
+      const int ritem = item - (cut.start + cut.nfull);            // index among the split items of this group
+      char* rec = records + ((((int64_t)b * 8 + xcd) * G.spx + jpart) * 2 + seg) * (int64_t)REC_B + wave * REC_WAVE_B;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, REC_WAVE_B, 0x00020000);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt][8 * s2 + j], scale_log2, -m_run));
-          psum += p;
-          pf[kt][s2][j] = (__bf16)p;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 vv = {o_acc[i][4 * g + 0], o_acc[i][4 * g + 1], o_acc[i][4 * g + 2], o_acc[i][4 * g + 3]};
+          const u32x4 w = __builtin_bit_cast(u32x4, vv);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs, (i * 4 + g) * 1024 + lane * 16, 0, 16 /* sc1: write-through */);
         }
-    l_run += psum;
-
-    // ---- Oᵀ += Vᵀ·Pᵀ : element j of lane-half hh of k-step (kt,s) is key 32kt + 16s + 8(j>>2) + 4hh + (j&3)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const s16x4 lo = tr_read(vp[0][dt] + SB + kt * 8192 + s2 * 4096);
-          const s16x4 hi = tr_read(vp[1][dt] + SB + kt * 8192 + s2 * 4096);
-          const bf16x8 vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi),
-                                                    0, 1, 2, 3, 4, 5, 6, 7);
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], o_acc[dt], 0, 0, 0);
+      {
+        const float2 mlf = {m_run, l_run};
+        const u32x2 ml = __builtin_bit_cast(u32x2, mlf);
+        __builtin_amdgcn_raw_buffer_store_b64(ml, rs, 16384 + lane * 8, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+      __syncthreads();
+      int* cnt = counters + (int64_t)b * G.NI + item;
+      // which splitting workgroups cover this item (same closed forms on every workgroup; 32-bit scalar arithmetic)
+      const unsigned U = (unsigned)cut.rem * (unsigned)ntiles, spx = (unsigned)G.spx;
+      const unsigned a = (unsigned)ritem * (unsigned)ntiles, bnd = a + (unsigned)ntiles;
+      const int j_first = (int)(((a + 1) * spx + U - 1) / U) - 1;
+      const int j_last = min(G.spx - 1, (int)((bnd * spx + U - 1) / U) - 1);
+      const int nparts = j_last - j_first + 1;
+      volatile int* flag = reinterpret_cast<volatile int*>(smem);
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == nparts - 1) ? 1 : 0;
+        if (last) {
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // drop this CU's stale lines
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        *flag = last;
       }
-  };
-
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  const int nfull = S / BKV;                   // tiles with all 64 keys valid
-  stage(0, 0, BKV > S);
-  int t = 0;
-  for (; t + 2 < nfull; t += 2) {              // tiles t, t+1 and the tiles they stage (t+1, t+2) are all full
-    tile(S0{}, std::false_type{}, t);
-    tile(S1{}, std::false_type{}, t + 1);
-  }
-  for (; t < ntiles; ++t) {                    // at most 3 tiles
-    if (t & 1) tile(S1{}, std::true_type{}, t);
-    else tile(S0{}, std::true_type{}, t);
-  }
-
-  // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = 32dt + (r&3) + 8(r>>2) + 4hh
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  const int qrow = q0 + wave * 32 + l31;
-  const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
-  if (wide) {
-    rt_store_o_rows(O + b * stride_ob + (int64_t)min(qrow, S - 1) * ldo + head * DH, qrow < S, hh, o_acc, inv);
-  } else if (qrow < S) {
-    bf16_t* op = O + b * stride_ob + (int64_t)qrow * ldo + head * DH + 4 * hh;
+      __syncthreads();
+      const int last = __builtin_amdgcn_readfirstlane(*flag);
+      if (last) {
+        // record of splitting workgroup j for this item: its second segment when the item starts after the run does
+        auto rec_of = [&](int j) -> const char* {
+          const unsigned lo_j = (unsigned)j * U / spx;
+          const int sj = (a > lo_j) ? 1 : 0;
+          return records + ((((int64_t)b * 8 + xcd) * G.spx + j) * 2 + sj) * (int64_t)REC_B + wave * REC_WAVE_B;
+        };
+        // pass 1: common max; pass 2: weighted sum in run order
+        float M = -INFINITY;
+        for (int j = j_first; j <= j_last; ++j) {
+          const char* rj = rec_of(__builtin_amdgcn_readfirstlane(j));
+          M = fmaxf(M, *reinterpret_cast<const float*>(rj + 16384 + lane * 8));
+        }
+        float L = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w;
-        w[0] = pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv);
-        w[1] = pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+          for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+        for (int j = j_first; j <= j_last; ++j) {
+          const char* rj = rec_of(__builtin_amdgcn_readfirstlane(j));
+          const float2 ml = *reinterpret_cast<const float2*>(rj + 16384 + lane * 8);
+          const float wgt = __builtin_amdgcn_exp2f(ml.x - M);
+          L = __builtin_fmaf(ml.y, wgt, L);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(rj + (i * 4 + g) * 1024 + lane * 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o_acc[i][4 * g + e] = __builtin_fmaf(v[e], wgt, o_acc[i][4 * g + e]);
+            }
+        }
+        l_run = L;
       }
+      if (!last) continue;
+    }
+
+    // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = 32dt + (r&3) + 8(r>>2) + 4hh
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
+    if (wide) {
+      rt_store_o_rows(O + b * stride_ob + (int64_t)min(qrow, S - 1) * ldo + head * DH, qrow < S, hh, o_acc, inv);
+    } else if (qrow < S) {
+      bf16_t* op = O + b * stride_ob + (int64_t)qrow * ldo + head * DH + 4 * hh;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 w;
+          w[0] = pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv);
+          w[1] = pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+        }
+    }
   }
 }
 
+int g_slots_per_xcd = 0;   // 2 workgroups per CU, CUs / 8 per XCD group (queried once)
 
-// ---------------------------------------------------------------------------------------------------
-// Software-pipelined variant (opt-in: RT_ATTN_VARIANT=pipe). Same tiling, layouts and arithmetic as attention_fwd_kernel; what changes is the
-// order of issue inside a wave, so that the MFMA pipe and the vector ALU work at the same time instead of in turns:
-//   iteration t:   Sᵀ(t+1) = K(t+1)·Qᵀ   (16 MFMAs)   ∥  exp2 / row-sum / bf16 pack of three quarters of tile t
-//                  Oᵀ += Vᵀ(t)·Pᵀ(t)     (8 MFMAs)    ∥  the last quarter of tile t
-//                                         (8 MFMAs)    ∥  row max of tile t+1, rescale decision
-// Each MFMA is followed by its slice of vector work and a scheduling fence, so the emitted order is the written order.
-// K is staged two tiles ahead and V one tile ahead (2 + 2 ring slots, one barrier per tile); LDS fragments are read two
-// MFMAs ahead of their use.
-// ---------------------------------------------------------------------------------------------------
-constexpr int K_SLOT_B = TILE_B;              // K slots at 0 and TILE_B, V slots at 2·TILE_B and 3·TILE_B
-constexpr int V_BASE_B = 2 * TILE_B;
-#ifndef RT_ATTN_PF
-#define RT_ATTN_PF 2
-#endif
-constexpr int PF = RT_ATTN_PF;                 // LDS fragments are read PF MFMAs ahead of their use
-
-__global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_pipe_kernel(
-    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* O,
-    int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob, int S, int H, float scale_log2) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // [K0 | K1 | V0 | V1]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * BQ;
-
-  const bf16_t* Qb = Q + b * stride_b + head * DH;
-  const bf16_t* Kb = K + b * stride_b + head * DH;
-  const bf16_t* Vb = V + b * stride_b + head * DH;
-
-  bf16x8 qf[8];
-  {
-    const int qrow = min(q0 + wave * 32 + l31, S - 1);
-    const bf16_t* qp = Qb + (int64_t)qrow * ld + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-  }
-
-  // ---- staging (see attention_fwd_kernel): wave w stages pieces 4w..4w+3 (4 rows each) of a tile
-  const int srow = lane >> 4, spc = lane & 15;
-  int srow_t[4];
-  uint32_t soff[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    srow_t[p] = (wave * 4 + p) * 4 + srow;
-    soff[p] = ((uint32_t)srow_t[p] * (uint32_t)ld + (uint32_t)((spc ^ swz(srow_t[p])) << 3)) * 2u;
-  }
-  // DMA by buffer_load ... lds: descriptor (4 SGPRs) + loop-invariant VGPR offset + per-tile SGPR offset, so staging costs no
-  // vector ALU work and no 64-bit address registers. num_records = 2^32-1: rows are clamped here, not by the range check.
-  const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, -1, 0x00020000);
-  const int tile_stride_b = BKV * (int)ld * 2;           // bytes between tiles (host checks S*ld*2 < 2^31)
-  auto stage_one = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_base, int tix, bool clamp) {
-    const int kv0 = tix * BKV;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      uint32_t off = soff[p];
-      if (clamp)
-        off = ((uint32_t)(min(kv0 + srow_t[p], S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(srow_t[p])) << 3)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + lds_base + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+int slots_per_xcd() {
+  if (g_slots_per_xcd == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-  };
-
-  lds_cptr kp[8];
-  {
-    const int ksw = swz(l31);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kp[ks] = (lds_cptr)smem + (l31 * 256 + (((2 * ks + hh) ^ ksw) << 4));
+    const char* e = getenv("RT_ATTN_SLOTS_PER_XCD");   // A/B and tests only
+    g_slots_per_xcd = e ? atoi(e) : (cus / 8) * 2;
+    if (g_slots_per_xcd < 1) g_slots_per_xcd = 1;
   }
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
-  const int tg1 = (lane >> 4) & 1;
-  lds_cptr vp[2][4];
-  {
-    const int cl = tg1 * 2 + (tp >> 1);
-    const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      vp[0][dt] = (lds_cptr)smem + V_BASE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
-      vp[1][dt] = (lds_cptr)smem + V_BASE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
-    }
-  }
+  return g_slots_per_xcd;
+}
 
-  f32x16 o_acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x16 sc[2][2];                             // score tiles by tile parity: [t & 1][32-key half]
-
-  const int ntiles = (S + BKV - 1) / BKV;
-  const int nfull = S / BKV;
-
-  // K fragment i (= 32-key half i>>3, k-step i&7) of the K slot at byte offset kb
-  auto k_read = [&](int i, int kb) -> bf16x8 {
-    return *(const __attribute__((address_space(3))) bf16x8*)(kp[i & 7] + kb + (i >> 3) * 8192);
-  };
-  // Vᵀ fragment n (= k-step n>>2 of the tile (16 keys each), d block n&3) of the V slot at byte offset vb
-  auto v_read = [&](int n, int vb) -> bf16x8 {
-    const int dt = n & 3, step = n >> 2;
-    const s16x4 lo = tr_read(vp[0][dt] + vb + step * 4096);
-    const s16x4 hi = tr_read(vp[1][dt] + vb + step * 4096);
-    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-  auto mask_tile = [&](f32x16 (&sx)[2], int t) {   // keys >= S of tile t
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * BKV + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (key >= S) sx[kt][r] = -INFINITY;
-      }
-  };
-  // row max of a score tile (two chains), both 32-key halves of the row combined across lane <-> lane+32
-  auto row_max_finish = [&](float ma, float mb) -> float {
-    float mx = fmaxf(ma, mb);
-    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-    return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) * scale_log2;
-  };
-  // deferred rescale (see attention_fwd_kernel): only when some row's max outgrew the one it is normalised with
-  auto decide = [&](float mx) {
-    if (__any(mx - m_run > RESCALE_THR)) {
-      asm volatile("" ::: "memory");
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-    }
-  };
-
-  bf16x8 pf[2][2];
-  float psum = 0.f;
-  // softmax numerator of element e (0..31) of the current tile: half e>>4, register e&15 -> operand pf[e>>4][(e>>3)&1][e&7]
-  auto soft = [&](const f32x16 (&cur)[2], int e) {
-    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[e >> 4][e & 15], scale_log2, -m_run));
-    psum += p;
-    pf[e >> 4][(e >> 3) & 1][e & 7] = (__bf16)p;
-  };
-
-  auto iteration = [&](auto par_c, auto tail_c, int t) {
-    constexpr int PAR = decltype(par_c)::value;          // t & 1
-    constexpr bool TAIL = decltype(tail_c)::value;       // last iterations: guarded staging, masked keys
-    constexpr int KB_NEXT = (PAR ^ 1) * K_SLOT_B;        // K(t+1)
-    constexpr int VB_CUR = PAR * TILE_B;                 // V(t), relative to V_BASE_B (folded into vp)
-    f32x16 (&cur)[2] = sc[PAR];
-    f32x16 (&nxt)[2] = sc[PAR ^ 1];
-    const bool has_next = TAIL ? (t + 1 < ntiles) : true;
-
-    rt_dma_barrier();    // K(t+1), V(t) landed (every wave's vmcnt(0), then the barrier); K slot PAR and V slot PAR^1 are free
-    if constexpr (!TAIL) {
-      stage_one(rsrcK, PAR * K_SLOT_B, t + 2, false);
-      stage_one(rsrcV, V_BASE_B + (PAR ^ 1) * TILE_B, t + 1, false);
-    } else {
-      if (t + 2 < ntiles) stage_one(rsrcK, PAR * K_SLOT_B, t + 2, (t + 3) * BKV > S);
-      if (t + 1 < ntiles) stage_one(rsrcV, V_BASE_B + (PAR ^ 1) * TILE_B, t + 1, (t + 2) * BKV > S);
-    }
-    psum = 0.f;
-
-    // ---- phase 1: Sᵀ(t+1) ∥ softmax numerators 0..23 of tile t
-    if (has_next) {
-      bf16x8 kf[PF + 1];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) kf[i] = k_read(i, KB_NEXT);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i + PF < 16) kf[(i + PF) % (PF + 1)] = k_read(i + PF, KB_NEXT);
-        const int kt = i >> 3, ks = i & 7;
-        if (ks == 0) {
-          f32x16 z;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) z[r] = 0.f;
-          nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % (PF + 1)], qf[ks], z, 0, 0, 0);
-        } else {
-          nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % (PF + 1)], qf[ks], nxt[kt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = (3 * i) / 2; e < (3 * (i + 1)) / 2; ++e) soft(cur, e);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 24; ++e) soft(cur, e);
-    }
-
-    // ---- phase 2: Oᵀ += Vᵀ(t)·Pᵀ(t) ∥ numerators 24..31, then ∥ row max of tile t+1
-    if (TAIL && has_next) mask_tile(nxt, t + 1);
-    float ma = -INFINITY, mb = -INFINITY;
-    {
-      bf16x8 vf[PF + 1];
-#pragma unroll
-      for (int n = 0; n < PF; ++n) vf[n] = v_read(n, VB_CUR);
-#pragma unroll
-      for (int n = 0; n < 16; ++n) {
-        if (n + PF < 16) vf[(n + PF) % (PF + 1)] = v_read(n + PF, VB_CUR);
-        const int kt = n >> 3, s2 = (n >> 2) & 1, dt = n & 3;
-        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[n % (PF + 1)], pf[kt][s2], o_acc[dt], 0, 0, 0);
-        if (n < 8) {
-          soft(cur, 24 + n);
-        } else if (has_next) {
-          const int g = n - 8;           // values 4g..4g+3 of the 32: two per chain
-          ma = max3f(ma, nxt[0][2 * g], nxt[0][2 * g + 1]);
-          mb = max3f(mb, nxt[1][2 * g], nxt[1][2 * g + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    l_run += psum;
-    if (has_next) decide(row_max_finish(ma, mb));
-  };
-
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  // ---- prologue: K(0), V(0), K(1) in flight; Sᵀ(0) and its row max computed alone
-  stage_one(rsrcK, 0, 0, BKV > S);
-  stage_one(rsrcV, V_BASE_B, 0, BKV > S);
-  if (ntiles > 1) stage_one(rsrcK, K_SLOT_B, 1, 2 * BKV > S);
-  rt_dma_barrier();
-  {
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[0][kt][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) sc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_read(kt * 8 + ks, 0), qf[ks], sc[0][kt], 0, 0, 0);
-    }
-    if (BKV > S) mask_tile(sc[0], 0);
-    float ma = -INFINITY, mb = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      ma = max3f(ma, sc[0][0][2 * g], sc[0][0][2 * g + 1]);
-      mb = max3f(mb, sc[0][1][2 * g], sc[0][1][2 * g + 1]);
-    }
-    decide(row_max_finish(ma, mb));
-  }
-  int t = 0;
-  for (; t + 3 < nfull; t += 2) {              // iterations t, t+1: tiles up to t+3 are full
-    iteration(P0{}, std::false_type{}, t);
-    iteration(P1{}, std::false_type{}, t + 1);
-  }
-  for (; t < ntiles; ++t) {                    // at most 4 iterations
-    if (t & 1) iteration(P1{}, std::true_type{}, t);
-    else iteration(P0{}, std::true_type{}, t);
-  }
-
-  // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = 32dt + (r&3) + 8(r>>2) + 4hh
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  const int qrow = q0 + wave * 32 + l31;
-  const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
-  if (wide) {
-    rt_store_o_rows(O + b * stride_ob + (int64_t)min(qrow, S - 1) * ldo + head * DH, qrow < S, hh, o_acc, inv);
-  } else if (qrow < S) {
-    bf16_t* op = O + b * stride_ob + (int64_t)qrow * ldo + head * DH + 4 * hh;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w;
-        w[0] = pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv);
-        w[1] = pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
-      }
-  }
+AttnGeom make_geom(int S, int H, bool want_split) {
+  AttnGeom G;
+  G.S = S;
+  G.H = H;
+  G.nqb = (S + BQ - 1) / BQ;
+  G.ntiles = (S + BKV - 1) / BKV;
+  G.NI = H * G.nqb;
+  G.spx = slots_per_xcd();
+  G.split = want_split ? 1 : 0;
+  return G;
 }
 
 }  // namespace
 
+// Workspace of the key-split tail for (B, S, H) on the current device: item counters (zero before first use; the kernel
+// leaves them zero) followed by the partial records. 0 when no item of this shape would be split.
+extern "C" int64_t rt_attention_ws_bytes(int32_t B, int32_t S, int32_t H) {
+  if (B < 1 || S < 1 || H < 1) return 0;
+  static const bool off = getenv("RT_ATTN_SPLIT") && getenv("RT_ATTN_SPLIT")[0] == '0';
+  if (off) return 0;
+  const AttnGeom G = make_geom(S, H, true);
+  bool any = false;
+  for (int x = 0; x < 8; ++x) any = any || group_cut(G, x).rem > 0;
+  if (!any) return 0;
+  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
+  return cnt_b + (int64_t)B * 8 * G.spx * 2 * REC_B;
+}
+
 extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b,
                                 int64_t ldo, int64_t stride_ob, int32_t B, int32_t S, int32_t H, float scale,
-                                void* stream) {
+                                void* ws, int64_t ws_bytes, void* stream) {
   if (!q || !k || !v || !o || B < 1 || S < 1 || H < 1) return RT_E_BADARG;
   if (!RT_ALIGNED(q, 16) || !RT_ALIGNED(k, 16) || !RT_ALIGNED(v, 16) || !RT_ALIGNED(o, 8) || ld % 8 || stride_b % 8 ||
       ldo % 4 || stride_ob % 4)
     return RT_E_ALIGN;
   if (ld < (int64_t)H * DH || ldo < (int64_t)H * DH) return RT_E_SHAPE;
   if ((int64_t)(S + BKV) * ld * 2 >= (int64_t)1 << 31) return RT_E_SHAPE;      // per-tile byte offsets are 32-bit
-  const dim3 grid((S + BQ - 1) / BQ, H, B);
-  // RT_ATTN_VARIANT=pipe selects the software-pipelined schedule: +4 % in isolation at S >= 4608, equal inside the model
-  // (2.203 vs 2.206 s/image) and slower at S = 768, so the plain kernel stays the default (attention anatomy).
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("RT_ATTN_VARIANT");
-    variant = (e && e[0] == 'p') ? 1 : 0;
-  }
-  if (variant == 0)
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,
-                       scale * 1.4426950408889634f);
-  else
-    hipLaunchKernelGGL(attention_fwd_pipe_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, S, H,
-                       scale * 1.4426950408889634f);
+  if ((int64_t)((S + BQ - 1) / BQ) * H * ((S + BKV - 1) / BKV + 1) * slots_per_xcd() >= ((int64_t)1 << 31)) return RT_E_SHAPE;   // 32-bit run arithmetic
+  const int64_t need = rt_attention_ws_bytes(B, S, H);
+  const bool split = ws != nullptr && need > 0;
+  if (split && (ws_bytes < need || !RT_ALIGNED(ws, 256))) return RT_E_BADARG;
+  const AttnGeom G = make_geom(S, H, split);
+  int wmax = 0;
+  for (int x = 0; x < 8; ++x) wmax = group_slots(G, x) > wmax ? group_slots(G, x) : wmax;
+  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
+  const dim3 grid(8 * wmax, B);
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(ATT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob,
+                     scale * 1.4426950408889634f, G, split ? (int*)ws : nullptr, split ? (char*)ws + cnt_b : nullptr);
   return rt_hip_status();
 }

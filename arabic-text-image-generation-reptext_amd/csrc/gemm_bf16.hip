@@ -99,7 +99,7 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     for (int j = 0; j < 4; ++j) { rcur[j] = rnext[j]; acur[j] = anext[j]; }
     if ((g.res || g.add2) && i + 1 < 8) fetch_row(i + 1);
     const int mc = min(m, g.M - 1);
-    const float rs = g.rowscale ? g.rowscale[mc % rpb] * g.alpha : g.alpha;
+    const float rs = g.rowscale ? g.rowscale[(int64_t)bidx * g.stride_rowscale + mc % rpb] * g.alpha : g.alpha;
     u32x2 packed[4];                                   // bf16 results of the 4 fragment columns (wide-store path)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

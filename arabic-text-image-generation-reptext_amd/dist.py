@@ -6,6 +6,10 @@ conditioning once (T5/CLIP embeddings, packed glyph-hint latents, regional masks
 buffer over RCCL/xGMI; after that there is no data-path collective — no all-reduce, no per-step traffic.
 Initial noise is NOT broadcast: every rank derives it from per-sample seeds, so a sample's latents are identical for
 any world size.
+
+Every conditioning tensor carries a leading sample dimension G: either the global batch (each image has its own prompt
+and glyph hints — BASELINE config 3's 32 images) or 1 (one prompt shared by the whole batch; expanded per rank, so the
+wire carries it once). A rank keeps rows [lo, hi) of the global batch (`shard_range`, `Conditioning.shard`).
 """
 from __future__ import annotations
 
@@ -25,18 +29,36 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 @dataclass
 class Conditioning:
-    """What rank 0 computes once per prompt and every rank needs (shared across the batch)."""
+    """What rank 0 computes once per call and every rank needs. Leading dimension G of every tensor: the global batch
+    (per-sample prompts / hints / masks) or 1 (shared by all samples)."""
 
-    prompt_embeds: torch.Tensor          # [1, L, joint_dim]
-    pooled: torch.Tensor                 # [1, pooled_dim]
-    hints: List[torch.Tensor]            # per text line [1, N, in+extra]
-    masks: List[torch.Tensor]            # per text line [N] (fp32 values in [0,1])
+    prompt_embeds: torch.Tensor          # [G, L, joint_dim]
+    pooled: torch.Tensor                 # [G, pooled_dim]
+    hints: List[torch.Tensor]            # per text line [G, N, in+extra]
+    masks: List[torch.Tensor]            # per text line [G, N] (fp32 values in [0,1]); legacy [N] is read as [1, N]
+
+    def __post_init__(self):
+        self.masks = [m if m.dim() == 2 else m.reshape(1, -1) for m in self.masks]
 
     def spec(self) -> List[Tuple[str, Tuple[int, ...]]]:
         out = [("prompt_embeds", tuple(self.prompt_embeds.shape)), ("pooled", tuple(self.pooled.shape))]
         out += [(f"hint{i}", tuple(h.shape)) for i, h in enumerate(self.hints)]
         out += [(f"mask{i}", tuple(m.shape)) for i, m in enumerate(self.masks)]
         return out
+
+    def shard(self, lo: int, hi: int) -> "Conditioning":
+        """Rows [lo, hi) of the global batch: tensors with G > 1 are sliced, shared ones (G == 1) expanded to hi - lo rows
+        (views; `.contiguous()` where a kernel needs it)."""
+        n = hi - lo
+
+        def take(t):
+            if t.shape[0] == 1:
+                return t.expand(n, *t.shape[1:])
+            if t.shape[0] < hi:
+                raise ValueError(f"conditioning holds {t.shape[0]} samples, shard [{lo}, {hi}) asked")
+            return t[lo:hi]
+
+        return Conditioning(take(self.prompt_embeds), take(self.pooled), [take(h) for h in self.hints], [take(m) for m in self.masks])
 
 
 def _flatten(c: Conditioning, dtype) -> torch.Tensor:
@@ -50,9 +72,14 @@ def broadcast_conditioning(c: Optional[Conditioning], spec: Sequence[Tuple[str, 
 
     Non-source ranks pass ``c=None`` and the static ``spec`` (names + shapes) all ranks agree on. fp32 on the wire keeps
     the bilinear regional masks exact (bf16 would round them); embeddings/hints are bf16 values, so they survive the
-    round trip bit-exactly. Payload at C2 with one text line: (512*4096 + 768 + 4096*128 + 4096) * 4 B ~ 10 MiB —
-    latency-bound on xGMI, issued once per prompt."""
-    n = sum(int(torch.tensor(s).prod()) for _, s in spec)
+    round trip bit-exactly. Payload at C2 with one shared text line: (512*4096 + 768 + 4096*128 + 4096) * 4 B ~ 10 MiB;
+    with 32 per-sample prompts and hints (config 3) 32x that = 340 MiB ~ a few ms on xGMI — issued once per call."""
+    n = 0
+    for _, shape in spec:
+        k = 1
+        for s in shape:
+            k *= int(s)
+        n += k
     if dist.get_rank() == src:
         if c is None:
             raise ValueError("source rank must provide the conditioning")
@@ -68,7 +95,7 @@ def broadcast_conditioning(c: Optional[Conditioning], spec: Sequence[Tuple[str, 
     for name, shape in spec:
         k = 1
         for s in shape:
-            k *= s
+            k *= int(s)
         t = flat[o : o + k].reshape(shape)
         out[name] = t.to(mask_dtype) if name.startswith("mask") else t.to(dtype)
         o += k

@@ -102,47 +102,123 @@ class TimeTextEmbedParams(nn.Module):
         self.text_embedder = mlp(pooled_dim)
 
 
-class WeightsIO:
-    """Local-path checkpoint IO shared by the models: config.json + *.safetensors (sharded or not).
+def hf_cache_dirs():
+    """The hub cache root, by huggingface_hub's precedence: HF_HUB_CACHE, HUGGINGFACE_HUB_CACHE, $HF_HOME/hub,
+    ~/.cache/huggingface/hub — the first one that is set is THE cache (no network is ever touched)."""
+    for env in ("HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE"):
+        if os.environ.get(env):
+            return [os.environ[env]]
+    if os.environ.get("HF_HOME"):
+        return [os.path.join(os.environ["HF_HOME"], "hub")]
+    return [os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub")]
 
-    Mirrors the subset of diffusers' ModelMixin.from_pretrained the reference uses (infer.py:30-33) for LOCAL
-    directories only — hub ids cannot resolve offline and raise."""
+
+def resolve_model_path(name_or_path: str, revision: Optional[str] = None) -> str:
+    """A local directory as it is; a hub id ("ORG/NAME", as infer.py:30-31 passes them) through the LOCAL hub cache layout
+    ``<cache>/models--ORG--NAME/snapshots/<commit>/`` (``refs/<revision or main>`` names the commit; else the newest snapshot).
+    Nothing is downloaded: a hub id without a cached snapshot raises with the paths that were tried."""
+    if os.path.isdir(name_or_path):
+        return name_or_path
+    tried = []
+    if "/" in name_or_path and not name_or_path.startswith((".", "/")) and name_or_path.count("/") == 1:
+        folder = "models--" + name_or_path.replace("/", "--")
+        for root in hf_cache_dirs():
+            repo = os.path.join(root, folder)
+            tried.append(repo)
+            snaps = os.path.join(repo, "snapshots")
+            if not os.path.isdir(snaps):
+                continue
+            ref = os.path.join(repo, "refs", revision or "main")
+            if os.path.isfile(ref):
+                with open(ref) as f:
+                    cand = os.path.join(snaps, f.read().strip())
+                if os.path.isdir(cand):
+                    return cand
+            if revision and os.path.isdir(os.path.join(snaps, revision)):
+                return os.path.join(snaps, revision)
+            cands = [os.path.join(snaps, d) for d in os.listdir(snaps) if os.path.isdir(os.path.join(snaps, d))]
+            if cands:
+                return max(cands, key=os.path.getmtime)
+    raise OSError(
+        f"'{name_or_path}' is neither a local directory nor a hub id with a snapshot in the local hub cache "
+        f"(looked for {tried or 'no cache path: not an ORG/NAME id'}). There is no network access on this path: download the "
+        "snapshot elsewhere and point HF_HOME / HF_HUB_CACHE at it, or pass the directory.")
+
+
+class WeightsIO:
+    """Checkpoint IO shared by the models: config.json + *.safetensors (single file or sharded with an index).
+
+    Mirrors the subset of diffusers' ModelMixin.from_pretrained the reference uses (infer.py:30-33): local directories and
+    hub ids that resolve through the local hub cache (resolve_model_path); nothing is ever downloaded."""
 
     config_name = "config.json"
     weights_name = "diffusion_pytorch_model.safetensors"
 
     @classmethod
     def _resolve_dir(cls, path: str, subfolder: Optional[str] = None) -> str:
-        p = os.path.join(path, subfolder) if subfolder else path
+        root = resolve_model_path(path)
+        p = os.path.join(root, subfolder) if subfolder else root
         if not os.path.isdir(p):
-            raise OSError(
-                f"{cls.__name__}.from_pretrained: '{path}' is not a local directory. Hub ids (e.g. 'Shakker-Labs/RepText') "
-                "need network access; download the snapshot and pass its path."
-            )
+            raise OSError(f"{cls.__name__}.from_pretrained: '{p}' does not exist (resolved from '{path}')")
         return p
 
-    @staticmethod
-    def _load_safetensors_dir(d: str) -> dict:
+    @classmethod
+    def _load_safetensors_dir(cls, d: str) -> dict:
+        """State dict of a model directory. With ``<weights_name>.index.json`` (diffusers' sharded layout, NB:2116-2118:
+        three transformer shards) exactly the shards its weight_map names are read and every key must come from the shard
+        the index assigns it to; otherwise every *.safetensors file of the directory."""
         from safetensors.torch import load_file
 
-        idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
-        files = []
+        idx = os.path.join(d, cls.weights_name + ".index.json")
+        sd = {}
         if os.path.isfile(idx):
             with open(idx) as f:
-                files = sorted(set(json.load(f)["weight_map"].values()))
-        else:
-            files = sorted(f for f in os.listdir(d) if f.endswith(".safetensors"))
+                wm = json.load(f)["weight_map"]
+            for fn in sorted(set(wm.values())):
+                fp = os.path.join(d, fn)
+                if not os.path.isfile(fp):
+                    raise OSError(f"{idx} names shard '{fn}', which is missing from {d}")
+                part = load_file(fp)
+                for k, v in part.items():
+                    if wm.get(k) == fn:
+                        sd[k] = v
+            missing = [k for k in wm if k not in sd]
+            if missing:
+                raise OSError(f"{len(missing)} tensors of {idx} were not found in their shards, e.g. {missing[:3]}")
+            return sd
+        files = sorted(f for f in os.listdir(d) if f.endswith(".safetensors"))
         if not files:
             raise OSError(f"no .safetensors files in {d}")
-        sd = {}
         for fn in files:
             sd.update(load_file(os.path.join(d, fn)))
         return sd
 
     def save_pretrained(self, d: str, max_shard_bytes: int = 10 << 30) -> None:
+        """config.json + weights in diffusers' layout: one file, or ``…-0000k-of-0000n.safetensors`` shards plus the index when
+        the state dict exceeds ``max_shard_bytes`` (diffusers' default is 10 GB; FLUX.1-dev's transformer ships as 3 shards)."""
         from safetensors.torch import save_file
 
         os.makedirs(d, exist_ok=True)
         self.config.save_json(os.path.join(d, self.config_name), type(self).__name__)
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
-        save_file(sd, os.path.join(d, self.weights_name))
+        total = sum(v.numel() * v.element_size() for v in sd.values())
+        if total <= max_shard_bytes:
+            save_file(sd, os.path.join(d, self.weights_name))
+            return
+        shards, cur, cur_b = [], {}, 0
+        for k, v in sd.items():
+            nb = v.numel() * v.element_size()
+            if cur and cur_b + nb > max_shard_bytes:
+                shards.append(cur)
+                cur, cur_b = {}, 0
+            cur[k] = v
+            cur_b += nb
+        shards.append(cur)
+        stem = self.weights_name[: -len(".safetensors")]
+        weight_map = {}
+        for i, part in enumerate(shards):
+            fn = f"{stem}-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(part, os.path.join(d, fn))
+            weight_map.update({k: fn for k in part})
+        with open(os.path.join(d, self.weights_name + ".index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2)

@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -42,6 +42,7 @@ class GemmGroup(C.Structure):
         ("rows_per_batch", C.c_int32), ("gelu_from", C.c_int32), ("out_f32", C.c_int32),
         ("alpha", C.c_float),
         ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
+        ("stride_rowscale", C.c_int64),
     ]
 
 
@@ -59,7 +60,8 @@ SIGNATURES = {
     "rt_rope_table": [_vp, _vp, _vp, _i32, C.POINTER(_i32), _f32, _vp],
     "rt_layernorm_modulate": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_qk_rmsnorm_rope": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
-    "rt_attention_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_attention_ws_bytes": [_i32, _i32, _i32],
+    "rt_attention_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
     "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
     "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fp8_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
@@ -92,7 +94,7 @@ SIGNATURES.update({
 })
 
 # entries that do not return a status code
-RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64, "rt_attention_fp8_vt_bytes": C.c_int64}
+RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64, "rt_attention_fp8_vt_bytes": C.c_int64, "rt_attention_ws_bytes": C.c_int64}
 
 _lib = None
 

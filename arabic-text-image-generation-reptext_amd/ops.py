@@ -60,7 +60,7 @@ class LinearProblem:
     a [M,K] or [B,M,K] bf16 views (unit inner stride); w [N,K] bf16; out [.., M, N] bf16|f32.
     gate f32: [B,N] view (one vector per batch) — or, for 2-D problems whose rows are batch-major,
     [M/rows_per_batch, N] with rows_per_batch set. res same dtype/shape as out (may alias it);
-    add2 bf16 same shape; rowscale f32 [rows_per_batch or M]."""
+    add2 bf16 same shape; rowscale f32 [rows_per_batch or M] shared by the batch, or [B, rows] (one vector per batch entry)."""
 
     a: torch.Tensor
     w: torch.Tensor
@@ -133,9 +133,12 @@ class LinearProblem:
             g.add2 = _dev(self.add2, "add2", BF16)
             g.ld2, g.stride2 = ld2, s2
         if self.rowscale is not None:
-            if self.rowscale.numel() != rows or not self.rowscale.is_contiguous():
-                raise ValueError("rowscale must be contiguous with rows_per_batch (or M) elements")
-            g.rowscale = _dev(self.rowscale, "rowscale", F32)
+            rsc = self.rowscale
+            if rsc.dim() == 2 and rsc.shape == (Bt, rows) and rsc.stride(1) == 1 and Bt > 1:
+                g.stride_rowscale = rsc.stride(0)                     # one mask per batch entry
+            elif rsc.numel() != rows or not rsc.is_contiguous():
+                raise ValueError("rowscale must be contiguous with rows_per_batch (or M) elements, or [batch, rows]")
+            g.rowscale = _dev(rsc, "rowscale", F32)
         g.rows_per_batch = rpb
         g.gelu_from = N if self.gelu_from is None else int(self.gelu_from)
         g.alpha = float(self.alpha)
@@ -283,8 +286,28 @@ def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, w
         _dev(wq_img, "wq_img", BF16), _dev(wk_img, "wk_img", BF16), _dev(cos, "cos", F32), _dev(sin, "sin", F32), B, S, T, H, float(eps), _stream()))
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, H: int, scale: Optional[float] = None) -> torch.Tensor:
-    """q,k,v [B,S,H*128] views (common strides) of one buffer; out [B,S,H*128] view (may alias q)."""
+_ATTN_WS = {}
+
+
+def _attention_workspace(B: int, S: int, H: int, device) -> Optional[torch.Tensor]:
+    """Workspace of rt_attention_fwd's key-split tail (ticket counters + partial records), one per (shape, device, stream):
+    two streams may run attention of the same shape at once (tower beside transformer). Zeroed once — the kernel leaves the
+    counters zero. None when this shape splits nothing."""
+    key = (B, S, H, str(device), _stream())
+    ws = _ATTN_WS.get(key, False)
+    if ws is False:
+        n = int(native.load().rt_attention_ws_bytes(B, S, H))
+        ws = torch.zeros(n, device=device, dtype=torch.uint8) if n > 0 else None
+        if len(_ATTN_WS) > 16:
+            _ATTN_WS.clear()
+        _ATTN_WS[key] = ws
+    return ws
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, H: int, scale: Optional[float] = None,
+              split: bool = True) -> torch.Tensor:
+    """q,k,v [B,S,H*128] views (common strides) of one buffer; out [B,S,H*128] view (may alias q). ``split=False`` runs every
+    128-row block as one full-length workgroup (no key-split tail; A/B and tests)."""
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         if t.dim() != 3 or t.stride(2) != 1 or t.shape[2] != H * 128:
             raise ValueError(f"{name}: need [B,S,{H*128}] with unit inner stride")
@@ -292,9 +315,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     if not (q.stride() == k.stride() == v.stride()) or k.shape != q.shape or v.shape != q.shape or out.shape != q.shape:
         raise ValueError("q,k,v must share shape and strides")
     sc = (128 ** -0.5) if scale is None else float(scale)
+    ws = _attention_workspace(B, S, H, q.device) if split else None
     native.check("rt_attention_fwd", native.load().rt_attention_fwd(
         _dev(q, "q", BF16), _dev(k, "k", BF16), _dev(v, "v", BF16), _dev(out, "out", BF16), q.stride(1), q.stride(0),
-        out.stride(1), out.stride(0), B, S, H, sc, _stream()))
+        out.stride(1), out.stride(0), B, S, H, sc, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream()))
     return out
 
 

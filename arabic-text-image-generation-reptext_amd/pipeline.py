@@ -127,40 +127,86 @@ class FluxControlNetPipeline:
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet=None, torch_dtype=None, **kwargs):
-        """Local-directory loader in the diffusers layout (model_index.json + one sub-folder per component; SURVEY.md
-        Appendix B). When their folders exist the text encoders load into reptext_amd.text_encoders (HIP kernels) and the
-        tokenizers through `transformers`; else they stay None and
-        the caller passes ``prompt_embeds``/``pooled_prompt_embeds``."""
-        root = pretrained_model_name_or_path
-        if not os.path.isdir(root):
-            raise OSError(f"FluxControlNetPipeline.from_pretrained: '{root}' is not a local directory; hub ids such as "
-                          "'black-forest-labs/FLUX.1-dev' need network access. Download the snapshot and pass its path.")
+        """Loader in the diffusers layout (``model_index.json`` + one sub-folder per component), as
+        infer.py:31-33 calls it. ``pretrained_model_name_or_path`` is a local directory or a hub id that resolves through the
+        LOCAL hub cache (modules.resolve_model_path: ``$HF_HOME/hub/models--ORG--NAME/snapshots/…``; nothing is downloaded).
+        ``model_index.json`` decides which components exist: the text encoders load into reptext_amd.text_encoders (HIP
+        kernels) and the tokenizers through `transformers` when listed and present; else they stay None and the caller
+        passes ``prompt_embeds``/``pooled_prompt_embeds``. Components passed as keyword arguments are taken as they are."""
+        from .modules import resolve_model_path
+
+        root = resolve_model_path(pretrained_model_name_or_path, kwargs.pop("revision", None))
         dt = torch_dtype or torch.bfloat16
+        index = {}
+        ip = os.path.join(root, "model_index.json")
+        if os.path.isfile(ip):
+            with open(ip) as f:
+                index = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        listed = lambda name: (not index) or (index.get(name) not in (None, [None, None]))
+        for required in ("transformer", "vae"):
+            if required not in kwargs and not (listed(required) and os.path.isdir(os.path.join(root, required))):
+                raise OSError(f"{cls.__name__}.from_pretrained: component '{required}' is neither passed nor present under {root}")
         sched_cfg = {}
         sp = os.path.join(root, "scheduler", "scheduler_config.json")
         if os.path.isfile(sp):
             with open(sp) as f:
                 sched_cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         known = set(FlowMatchEulerDiscreteScheduler().config.keys())
-        scheduler = FlowMatchEulerDiscreteScheduler(**{k: v for k, v in sched_cfg.items() if k in known})
+        scheduler = kwargs.pop("scheduler", None) or FlowMatchEulerDiscreteScheduler(**{k: v for k, v in sched_cfg.items() if k in known})
         transformer = kwargs.pop("transformer", None) or FluxTransformer2DModel.from_pretrained(root, torch_dtype=dt, subfolder="transformer")
         vae = kwargs.pop("vae", None) or AutoencoderKL.from_pretrained(root, torch_dtype=dt, subfolder="vae")
-        te = te2 = tok = tok2 = None
+        te, te2 = kwargs.pop("text_encoder", None), kwargs.pop("text_encoder_2", None)
+        tok, tok2 = kwargs.pop("tokenizer", None), kwargs.pop("tokenizer_2", None)
         try:
-            if os.path.isdir(os.path.join(root, "text_encoder")):
-                from transformers import CLIPTokenizer, T5TokenizerFast        # tokenisation is host-side string work
-
-                from .text_encoders import CLIPTextModel, T5EncoderModel     # the encoders themselves run on the HIP kernels
+            if te is None and listed("text_encoder") and os.path.isdir(os.path.join(root, "text_encoder")):
+                from .text_encoders import CLIPTextModel                 # the encoders themselves run on the HIP kernels
 
                 te = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", torch_dtype=dt)
-                tok = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer")
+            if te2 is None and listed("text_encoder_2") and os.path.isdir(os.path.join(root, "text_encoder_2")):
+                from .text_encoders import T5EncoderModel
+
                 te2 = T5EncoderModel.from_pretrained(root, subfolder="text_encoder_2", torch_dtype=dt)
-                tok2 = T5TokenizerFast.from_pretrained(root, subfolder="tokenizer_2")
+            if tok is None and listed("tokenizer") and os.path.isdir(os.path.join(root, "tokenizer")):
+                from transformers import CLIPTokenizer                   # tokenisation is host-side string work
+
+                tok = CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+            if tok2 is None and listed("tokenizer_2") and os.path.isdir(os.path.join(root, "tokenizer_2")):
+                from transformers import T5TokenizerFast
+
+                tok2 = T5TokenizerFast.from_pretrained(os.path.join(root, "tokenizer_2"))
         except Exception as e:  # pragma: no cover - depends on local files
             raise OSError(f"could not load text encoders from {root}: {e}") from e
+        if isinstance(controlnet, str):
+            controlnet = FluxControlNetModel.from_pretrained(controlnet, torch_dtype=dt)
         extra = {k: kwargs[k] for k in ("controlnet_inpaint",) if k in kwargs}
         return cls(scheduler=scheduler, vae=vae, text_encoder=te, tokenizer=tok, text_encoder_2=te2, tokenizer_2=tok2,
                    transformer=transformer, controlnet=controlnet, **extra)
+
+    def save_pretrained(self, root: str, max_shard_bytes: int = 10 << 30) -> None:
+        """Write the diffusers layout this class loads: model_index.json, scheduler/scheduler_config.json and one folder per
+        model component that has weights here (the ControlNet is a separate repository in the reference and is not part of it)."""
+        os.makedirs(root, exist_ok=True)
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.36.0"}
+        for name in ("transformer", "vae", "text_encoder", "text_encoder_2"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "save_pretrained"):
+                m.save_pretrained(os.path.join(root, name), max_shard_bytes=max_shard_bytes) if name in ("transformer", "vae") else m.save_pretrained(os.path.join(root, name))
+                index[name] = ["reptext_amd", type(m).__name__]
+            else:
+                index[name] = [None, None]
+        for name in ("tokenizer", "tokenizer_2"):
+            t = getattr(self, name, None)
+            if t is not None and hasattr(t, "save_pretrained"):
+                t.save_pretrained(os.path.join(root, name))
+                index[name] = ["transformers", type(t).__name__]
+            else:
+                index[name] = [None, None]
+        os.makedirs(os.path.join(root, "scheduler"), exist_ok=True)
+        with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+            json.dump(dict(_class_name="FlowMatchEulerDiscreteScheduler", **dict(self.scheduler.config)), f, indent=2)
+        index["scheduler"] = ["reptext_amd", "FlowMatchEulerDiscreteScheduler"]
+        with open(os.path.join(root, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
 
     def to(self, device=None, dtype=None):
         for m in self.components.values():
@@ -480,13 +526,36 @@ class FluxControlNetPipeline:
         B = latents.shape[0]
         tvals = timesteps.to(torch.float32).cpu().tolist()                 # host copies: no per-step device sync
         guidance = torch.full((B,), float(guidance_scale), device=device, dtype=torch.float32) if self.transformer.config.guidance_embeds else None
-        rowscales = [m.reshape(-1).to(torch.float32).contiguous() for m in masks]
+        # one regional mask per text line, shared by the batch ([1,N,1], the reference's form) or one per image ([B,N,1])
+        rowscales = [m.to(torch.float32).reshape(-1).contiguous() if m.shape[0] == 1 else m.to(torch.float32).reshape(m.shape[0], -1).contiguous() for m in masks]
         num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
         # adaLN vectors of every block for every step, once per image (timesteps/guidance/pooled are loop-invariant inputs)
         model_ts = [t / 1000.0 for t in tvals]
         tab_t = self.transformer.build_modulation_table(model_ts, guidance, pooled)
         fused_cn = isinstance(self.controlnet, FluxControlNetModel) and len(hints) > 0
         tab_c = self.controlnet.build_modulation_table(model_ts[: max(0, min(len(model_ts), cn_steps))], guidance, pooled) if fused_cn and cn_steps > 0 else None
+        # Loop-invariant work, once per image instead of once per step (the prompt and the hint latents do not change inside the
+        # loop): context_embedder(prompt) of both models, controlnet_x_embedder(hint) per text line. A callback that replaces
+        # prompt_embeds invalidates them (recomputed below).
+        static_t = self.transformer.prepare_static(prompt_embeds)
+        static_c = [self.controlnet.prepare_static(prompt_embeds, h) for h in hints] if fused_cn and cn_steps > 0 else []
+        # Which tower samples does the transformer read? Block i takes sample i // ceil(n_blocks / n_samples) (A.3): with 6
+        # samples against 19 double blocks the sixth is never consumed (Q5), so its block and zero-linear are not evaluated.
+        blocks_needed, sample_buf, single_buf = None, None, None
+        if fused_cn:
+            cnet = self.controlnet
+            n_cd, n_cs = len(cnet.transformer_blocks), len(cnet.single_transformer_blocks)
+            n_td, n_ts = len(self.transformer.transformer_blocks), len(self.transformer.single_transformer_blocks)
+            need_d = 0 if n_cd == 0 else (n_td - 1) // int(np.ceil(n_td / n_cd)) + 1
+            need_s = 0 if n_cs == 0 or n_ts == 0 else (n_ts - 1) // int(np.ceil(n_ts / n_cs)) + 1
+            blocks_needed = (min(need_d, n_cd), min(need_s, n_cs))
+            # sample buffers: allocated once per shape, written by the zero-linear epilogues every step (no per-step allocation)
+            Bc, N_, d_ = prompt_embeds.shape[0], latents.shape[1], cnet.inner_dim
+            key = (Bc, N_, d_, n_cd, n_cs, str(device))
+            if getattr(self, "_sample_cache", None) is None or self._sample_cache[0] != key:
+                mk = lambda n: [torch.empty(Bc, N_, d_, device=device, dtype=torch.bfloat16) for _ in range(n)]
+                self._sample_cache = (key, mk(n_cd), mk(n_cs))
+            sample_buf, single_buf = self._sample_cache[1], self._sample_cache[2]
         # fp32 master copy of the latents between steps (the models read its bf16 copy): the scheduler computes in fp32 anyway
         # (A.6); not rounding the STATE 28 times keeps the loop close to the fp32 reference path. Callbacks see the bf16 copy.
         lat32 = latents.to(torch.float32).contiguous()
@@ -503,10 +572,7 @@ class FluxControlNetPipeline:
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
                 self._side_stream = torch.cuda.Stream(device=device)
             side = self._side_stream
-            n_s = len(self.controlnet.transformer_blocks)
-            Bc, N_, d_ = prompt_embeds.shape[0], latents.shape[1], self.controlnet.inner_dim
-            sample_buf = [torch.empty(Bc, N_, d_, device=device, dtype=torch.bfloat16) for _ in range(n_s)]
-            sample_ev = [torch.cuda.Event() for _ in range(n_s)]
+            sample_ev = [torch.cuda.Event() for _ in range(len(self.controlnet.transformer_blocks))]
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(tvals):
                 if self.interrupt:
@@ -525,11 +591,20 @@ class FluxControlNetPipeline:
                                 txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs,
                                 return_dict=False, _rowscale=rowscales[line] if rowscales else None, _accumulate_into=sample_buf,
                                 _overwrite=(line == 0), _sample_events=sample_ev if line == len(hints) - 1 else None,
-                                _mods=tab_c.step(i), _ws_tag="tower")
-                    merged, events = sample_buf, sample_ev
+                                _mods=tab_c.step(i), _ws_tag="tower", _static=static_c[line], _blocks_needed=blocks_needed)
+                    merged, events = [b if k < blocks_needed[0] else None for k, b in enumerate(sample_buf)], sample_ev
                 for line, hint in enumerate(hints if events is None else ()):
                     if i >= cn_steps:                                                             # Q3
                         samples = single_samples = None
+                    elif fused_cn:
+                        # zero-linear epilogues write (line 0) or add to (later lines: PIPE:1076-1087) the preallocated buffers
+                        samples, single_samples = self.controlnet(
+                            hidden_states=latents, controlnet_cond=hint, controlnet_mode=control_mode, conditioning_scale=cn_scale,
+                            timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=prompt_embeds,
+                            txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs,
+                            return_dict=False, _rowscale=rowscales[line] if rowscales else None, _accumulate_into=sample_buf,
+                            _accumulate_single_into=single_buf, _overwrite=(line == 0), _mods=None if tab_c is None else tab_c.step(i),
+                            _static=static_c[line] if static_c else None, _blocks_needed=blocks_needed)
                     else:
                         rs = rowscales[line] if rowscales else None
                         samples, single_samples = self.controlnet(
@@ -546,7 +621,7 @@ class FluxControlNetPipeline:
                     hidden_states=latents, timestep=timestep, guidance=guidance, pooled_projections=pooled,
                     encoder_hidden_states=prompt_embeds, controlnet_block_samples=merged, controlnet_single_block_samples=merged_single,
                     txt_ids=text_ids, img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False,
-                    _mods=tab_t.step(i), _sample_events=events)[0]
+                    _mods=tab_t.step(i), _sample_events=events, _static=static_t)[0]
                 if events is not None:
                     torch.cuda.current_stream().wait_stream(side)     # the tower has finished reading `latents` (its last sample is unused, Q5)
                 self.scheduler.step_master_(noise_pred, lat32, latents)
@@ -556,7 +631,10 @@ class FluxControlNetPipeline:
                     if "latents" in out:
                         latents = out.pop("latents").to(torch.bfloat16).contiguous()
                         lat32 = latents.to(torch.float32)
-                    prompt_embeds = out.pop("prompt_embeds", prompt_embeds)
+                    if "prompt_embeds" in out:                       # the loop-invariant embeddings are no longer valid
+                        prompt_embeds = out.pop("prompt_embeds")
+                        static_t = self.transformer.prepare_static(prompt_embeds)
+                        static_c = [self.controlnet.prepare_static(prompt_embeds, h) for h in hints] if static_c else []
                 if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
                     bar.update()
         self._master_latents = lat32          # fp32 state of the loop; `latents` is its bf16 copy

@@ -226,7 +226,8 @@ class FluxControlNetPipeline(_BasePipeline):
         B = latents.shape[0]
         tvals = timesteps.to(torch.float32).cpu().tolist()
         guidance = torch.full((B,), float(guidance_scale), device=device, dtype=torch.float32) if self.transformer.config.guidance_embeds else None
-        rowscales = [m.reshape(-1).to(torch.float32).contiguous() for m in masks]
+        # one regional mask per text line, shared by the batch ([1,N,1], the reference's form) or one per image ([B,N,1])
+        rowscales = [m.to(torch.float32).reshape(-1).contiguous() if m.shape[0] == 1 else m.to(torch.float32).reshape(m.shape[0], -1).contiguous() for m in masks]
         num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
         model_ts = [t / 1000.0 for t in tvals]
         g_tab = guidance if guidance is None or pooled.shape[0] == B else guidance.expand(pooled.shape[0]).contiguous()
@@ -234,6 +235,23 @@ class FluxControlNetPipeline(_BasePipeline):
         n_cn = max(0, min(len(model_ts), cn_steps))
         tab_c = self.controlnet.build_modulation_table(model_ts[:n_cn], g_tab, pooled) if (hints and n_cn > 0) else None
         tab_i = self.controlnet_inpaint.build_modulation_table(model_ts[:n_cn], g_tab, pooled) if (hints and n_cn > 0) else None
+        # loop-invariant embeddings, once per call (see FluxControlNetPipeline._denoise)
+        static_t = self.transformer.prepare_static(pe)
+        static_c = [self.controlnet.prepare_static(pe, h) for h in hints] if (hints and n_cn > 0) else []
+        static_i = self.controlnet_inpaint.prepare_static(pe, hint_inp) if (hints and n_cn > 0) else None
+        # preallocated sample buffers; the sixth sample of a 6-block tower is never read by the 19-block transformer (Q5)
+        blocks_needed, sample_buf, single_buf = None, None, None
+        if hints and n_cn > 0:
+            c1, c2 = self.controlnet, self.controlnet_inpaint
+            n_cd, n_cs = len(c1.transformer_blocks), len(c1.single_transformer_blocks)
+            n_td, n_ts = len(self.transformer.transformer_blocks), len(self.transformer.single_transformer_blocks)
+            if (len(c2.transformer_blocks), len(c2.single_transformer_blocks)) == (n_cd, n_cs):
+                need_d = 0 if n_cd == 0 else (n_td - 1) // int(np.ceil(n_td / n_cd)) + 1
+                need_s = 0 if n_cs == 0 or n_ts == 0 else (n_ts - 1) // int(np.ceil(n_ts / n_cs)) + 1
+                blocks_needed = (min(need_d, n_cd), min(need_s, n_cs))
+            Bc, N_, d_ = pe.shape[0], latents.shape[1], c1.inner_dim
+            sample_buf = [torch.empty(Bc, N_, d_, device=device, dtype=torch.bfloat16) for _ in range(n_cd)]
+            single_buf = [torch.empty(Bc, N_, d_, device=device, dtype=torch.bfloat16) for _ in range(n_cs)]
         # fp32 master copy of the latents between steps (the models read its bf16 copy): the scheduler computes in fp32 anyway
         # (A.6); not rounding the STATE 28 times keeps the loop close to the fp32 reference path. Callbacks see the bf16 copy.
         lat32 = latents.to(torch.float32).contiguous()
@@ -253,8 +271,9 @@ class FluxControlNetPipeline(_BasePipeline):
                             hidden_states=latents, controlnet_cond=hint, controlnet_mode=control_mode, conditioning_scale=cn_scale,
                             timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=pe, txt_ids=text_ids,
                             img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, _rowscale=rs,
-                            _accumulate_into=merged if line > 0 else None, _accumulate_single_into=merged_single if line > 0 else None,
-                            _mods=None if tab_c is None else tab_c.step(i))
+                            _accumulate_into=sample_buf, _accumulate_single_into=single_buf, _overwrite=(line == 0),
+                            _mods=None if tab_c is None else tab_c.step(i), _static=static_c[line] if static_c else None,
+                            _blocks_needed=blocks_needed)
                     if line == 0:
                         merged, merged_single = samples, single_samples
                 # The inpaint tower's residuals are ADDED to the text towers' — and dropped when those are absent (INP:1231-1245:
@@ -264,11 +283,12 @@ class FluxControlNetPipeline(_BasePipeline):
                         hidden_states=latents, controlnet_cond=hint_inp, controlnet_mode=control_mode, conditioning_scale=cn_scale_inp,
                         timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=pe, txt_ids=text_ids,
                         img_ids=image_ids, joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False,
-                        _accumulate_into=merged, _accumulate_single_into=merged_single, _mods=None if tab_i is None else tab_i.step(i))
+                        _accumulate_into=sample_buf, _accumulate_single_into=single_buf, _mods=None if tab_i is None else tab_i.step(i),
+                        _static=static_i, _blocks_needed=blocks_needed)
                 noise_pred = self.transformer(
                     hidden_states=latents, timestep=timestep, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=pe,
                     controlnet_block_samples=merged, controlnet_single_block_samples=merged_single, txt_ids=text_ids, img_ids=image_ids,
-                    joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, _mods=tab_t.step(i))[0]
+                    joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, _mods=tab_t.step(i), _static=static_t)[0]
                 if cfg:
                     uncond, text = noise_pred[:B], noise_pred[B:]                          # chunk(2): negative first
                     if i > 0:
@@ -282,7 +302,11 @@ class FluxControlNetPipeline(_BasePipeline):
                     if "latents" in out:
                         latents = out.pop("latents").to(torch.bfloat16).contiguous()
                         lat32 = latents.to(torch.float32)
-                    pe = out.pop("prompt_embeds", pe)
+                    if "prompt_embeds" in out:                       # the loop-invariant embeddings are no longer valid
+                        pe = out.pop("prompt_embeds")
+                        static_t = self.transformer.prepare_static(pe)
+                        static_c = [self.controlnet.prepare_static(pe, h) for h in hints] if static_c else []
+                        static_i = self.controlnet_inpaint.prepare_static(pe, hint_inp) if static_i is not None else None
                 if i == len(tvals) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
                     bar.update()
         self._master_latents = lat32          # fp32 state of the loop; `latents` is its bf16 copy

@@ -23,6 +23,17 @@ class Transformer2DModelOutput:
     sample: torch.Tensor
 
 
+@dataclass
+class StaticEmbeds:
+    """Loop-invariant embeddings of one model for one call of the pipeline (``_MMDiTBase.prepare_static``): the prompt never
+    changes between denoising steps and neither do the hint latents, so ``context_embedder(prompt)`` (A.3 / CN:292) and
+    ``controlnet_x_embedder(cond)`` (CN:280) are evaluated once per image instead of once per step. Both are kept in the
+    residual stream's dtype; adding them back is exact (same operands as the per-step path, fp32 addition commutes)."""
+
+    ctx: torch.Tensor                     # [Bc, T, d]  context_embedder(encoder_hidden_states) + bias
+    hint: Optional[torch.Tensor] = None   # [Bc, N, d]  controlnet_x_embedder(controlnet_cond) + bias (towers only)
+
+
 class _MMDiTBase(nn.Module, WeightsIO):
     """Construction, planning and embedding steps common to the transformer and the ControlNet tower."""
 
@@ -139,6 +150,23 @@ class _MMDiTBase(nn.Module, WeightsIO):
                 g1000 = g1000.expand(ws.B).contiguous()
         return mmdit.time_text_embed(self.time_text_embed, ws, t1000.contiguous(), g1000, pooled)
 
+    def prepare_static(self, encoder_hidden_states: torch.Tensor, controlnet_cond: Optional[torch.Tensor] = None) -> StaticEmbeds:
+        """See StaticEmbeds. ``controlnet_cond`` [Bc,N,in+extra] only for models that own a ``controlnet_x_embedder``."""
+        self._ensure_plans()
+        d = self.inner_dim
+        xdt = torch.float32 if mmdit.RESIDUAL_F32 else torch.bfloat16
+        e = encoder_hidden_states.to(torch.bfloat16).contiguous()
+        ctx = torch.empty(e.shape[0], e.shape[1], d, device=e.device, dtype=xdt)
+        ops.linear(e, self.context_embedder.weight.data, ctx, bias=self.context_embedder.bias.data)
+        hint = None
+        if controlnet_cond is not None:
+            cond, cxw = self._padded_hint(controlnet_cond.to(torch.bfloat16))
+            if cond.shape[0] != e.shape[0]:
+                cond = cond.expand(e.shape[0], -1, -1) if cond.shape[0] == 1 else cond.repeat(e.shape[0] // cond.shape[0], 1, 1)
+            hint = torch.empty(e.shape[0], cond.shape[1], d, device=e.device, dtype=xdt)
+            ops.linear(cond.contiguous(), cxw, hint, bias=self.controlnet_x_embedder.bias.data)
+        return StaticEmbeds(ctx, hint)
+
     def build_modulation_table(self, timesteps, guidance, pooled) -> "mmdit.ModulationTable":
         """adaLN vectors of every block for every entry of ``timesteps`` (model-scale values, i.e. t/1000 as the pipeline
         passes them, PIPE:1048,1094) — see mmdit.ModulationTable. guidance [B] / pooled [B,P] as in ``forward``."""
@@ -185,9 +213,11 @@ class FluxTransformer2DModel(_MMDiTBase):
                 txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
                 controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False,
-                _mods: Optional["mmdit.StepMods"] = None, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None):
+                _mods: Optional["mmdit.StepMods"] = None, _sample_events: Optional[Sequence["torch.cuda.Event"]] = None,
+                _static: Optional[StaticEmbeds] = None):
         """``_sample_events[k]`` (optional): event another stream records when controlnet_block_samples[k] is complete; the
-        current stream waits for it right before the first block that consumes that sample."""
+        current stream waits for it right before the first block that consumes that sample. ``_static`` (optional): this
+        model's loop-invariant embeddings (prepare_static) — the text rows are copied instead of recomputed."""
         doubles, singles = self._ensure_plans()
         cfg = self.config
         B, N, _ = hidden_states.shape
@@ -200,9 +230,13 @@ class FluxTransformer2DModel(_MMDiTBase):
             if Bc % B:
                 raise ValueError("conditioning batch must be a multiple of the latent batch")
             hs = hs.repeat(Bc // B, 1, 1)
-        ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, ws.x[:, T:], bias=self.x_embedder.bias.data),
-                            P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, ws.x[:, :T],
-                              bias=self.context_embedder.bias.data)])
+        if _static is not None:
+            ws.x[:, :T].copy_(_static.ctx)                                   # device copy of the loop-invariant text rows
+            ops.linear(hs.contiguous(), self.x_embedder.weight.data, ws.x[:, T:], bias=self.x_embedder.bias.data)
+        else:
+            ops.linear_grouped([P(hs.contiguous(), self.x_embedder.weight.data, ws.x[:, T:], bias=self.x_embedder.bias.data),
+                                P(encoder_hidden_states.to(torch.bfloat16).contiguous(), self.context_embedder.weight.data, ws.x[:, :T],
+                                  bias=self.context_embedder.bias.data)])
         temb = None if _mods is not None else self._temb(ws, timestep, guidance, pooled_projections)
         cos, sin = self._rope(txt_ids, img_ids)
         nl, ns = len(doubles), len(singles)

@@ -183,9 +183,24 @@ class AutoencoderKL(nn.Module, WeightsIO):
     def device(self):
         return self.decoder.conv_in.weight.device
 
+    def _invalidate_derived(self):
+        """Drop every tensor derived from parameters (repacked conv weights, fused mid-attention q|k|v): they are rebuilt on
+        next use. Called whenever parameters are rewritten IN PLACE — load_state_dict and random_init_ copy into the existing
+        storage, so data_ptr() does not change and cannot serve as the cache key on its own."""
+        self._packed = {}
+        for m in self.modules():
+            if hasattr(m, "_qkv"):
+                del m._qkv
+
     def _apply(self, fn, *a, **k):
-        self._packed, self._pool, self._stats = {}, None, None
+        self._invalidate_derived()
+        self._pool, self._stats = None, None
         return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, sd, strict: bool = True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._invalidate_derived()
+        return out
 
     def random_init_(self, seed: int = 0):
         g = torch.Generator(device=self.device).manual_seed(seed)
@@ -199,7 +214,7 @@ class AutoencoderKL(nn.Module, WeightsIO):
                 p.data.copy_(1.0 + 0.1 * r)
             else:
                 p.data.copy_(0.05 * r)
-        self._packed = {}
+        self._invalidate_derived()
         return self
 
     @classmethod

@@ -29,7 +29,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed passes (images per GPU x batch)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=1, help="weak scaling (default): images per GPU per pass, fixed as N grows")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: TOTAL images per pass, fixed as N grows (BASELINE config 3: 32 over 8 GPUs); each rank runs its "
+                         "shard_range share; overrides --batch-per-gpu")
+    ap.add_argument("--shared-prompt", action="store_true",
+                    help="one prompt / hint / mask for the whole batch (broadcast once, expanded per rank) instead of one per image")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--inference-steps", type=int, default=28)
@@ -44,18 +49,29 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------- work model
-def flops_per_image(H, W, steps, lines, cfg_t, cfg_c):
+def tower_blocks_read(cfg_t, cfg_c):
+    """Double blocks of the tower whose samples the transformer consumes: block i of the transformer reads sample
+    i // ceil(n_t / n_c) (SURVEY A.3) — 5 of RepText's 6 against FLUX's 19 (quirk Q5). The pipeline does not evaluate the rest."""
+    n_t, n_c = cfg_t["num_layers"], cfg_c["num_layers"]
+    if n_c == 0 or cfg_c["num_single_layers"] > 0:
+        return n_c
+    return min(n_c, (n_t - 1) // math.ceil(n_t / n_c) + 1)
+
+
+def flops_per_image(H, W, steps, lines, cfg_t, cfg_c, tower_blocks=None):
+    """SURVEY §8d work model. ``tower_blocks``: double blocks of the tower actually evaluated (None = all, the reference's
+    count); the roofline fractions use the EXECUTED count so that skipped dead work does not inflate them."""
     d = cfg_t["num_attention_heads"] * cfg_t["attention_head_dim"]
     T, N = 512, (H // 16) * (W // 16)
     S = T + N
     block = 24 * S * d * d + 4 * S * S * d
     tr = (cfg_t["num_layers"] + cfg_t["num_single_layers"]) * block + 2 * N * 64 * d + 2 * T * 4096 * d + 2 * N * d * 64
-    L = cfg_c["num_layers"] + cfg_c["num_single_layers"]
+    L = (cfg_c["num_layers"] if tower_blocks is None else tower_blocks) + cfg_c["num_single_layers"]
     cn = L * block + L * 2 * N * d * d + 2 * N * 64 * d + 2 * N * (64 + cfg_c["extra_condition_channels"]) * d + 2 * T * 4096 * d
     return steps * (tr + lines * cn)
 
 
-def synthetic_glyph_hint(height, width, text="مرحبا"):
+def synthetic_glyph_hint(height, width, text="مرحبا", shift=0):
     """PIL-rendered Arabic glyph on black + bbox position/region masks (host, once). Falls back to a plain box when no
     font with Arabic coverage is installed (the hint only sets mask geometry for the benchmark)."""
     import numpy as np
@@ -63,7 +79,7 @@ def synthetic_glyph_hint(height, width, text="مرحبا"):
 
     img = Image.new("RGB", (width, height), (0, 0, 0))
     draw = ImageDraw.Draw(img)
-    pos = (int(width * 0.36), int(height * 0.2))
+    pos = (int(width * (0.10 + 0.08 * (shift % 7))), int(height * (0.10 + 0.11 * ((shift // 7) % 7))))
     try:
         font = ImageFont.truetype("DejaVuSans.ttf", max(height // 13, 12))
         draw.text(pos, text, font=font, fill=(255, 255, 255))
@@ -150,7 +166,10 @@ def pmc_traffic_bytes(kernel_key: str):
     FETCH_SIZE and --pmc WRITE_SIZE over this same command, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
     Counters cannot be read from inside the timed process, so the value is the last profiled one; null when absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+        path = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
+        if not os.path.isfile(path):
+            path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        with open(path) as f:
             d = json.load(f)
         if kernel_key.startswith("fp8:"):          # the passes over `bench.py --precision fp8`
             return int(d["fp8_run"]["kernels"][kernel_key[4:]]["hbm_bytes_per_launch_corrected"])
@@ -173,18 +192,48 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("RT_CPU_BASELINE_THREADS", "16"))))
 
 
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(cfg_t, H, W, steps, lines, cfg_c, budget_s=12.0):
-    """Oracle (fp32 torch CPU ops) on a bounded sample: whole MMDiT blocks at the C2 sequence length, extrapolated by
-    block count to one image. Returns the cpu_baseline JSON object."""
+    """The CPU path beside the GPU number: the fp32 oracle (stock torch CPU ops, kind "port") on the box's host
+    cores, on a bounded sample of about 20-30 s:
+      (1) BASELINE config 1 RUN IN FULL through oracle.denoise_loop — 256x256, 2 steps, T = 512, one masked text line, at the
+          real width (d = 3072, 24 heads, joint 4096) and a stated reduced depth (2+2 transformer, 1+0 tower: the full 19+38 /
+          6+0 stack is 57 GB of fp32 weights and minutes per step);
+      (2) whole MMDiT blocks at the C2 sequence length (S = 4608), extrapolated by block count to one C2 image — this is
+          `value`, in the metric's unit (images/sec)."""
     from oracle import flux_oracle as orc
 
     cores = usable_cores()
     torch.set_num_threads(cores)
     d = cfg_t["num_attention_heads"] * cfg_t["attention_head_dim"]
-    T, N = 512, (H // 16) * (W // 16)
+    # ---- (1) config 1 end to end at reduced depth
+    c1_t = dict(cfg_t, num_layers=2, num_single_layers=2)
+    c1_c = dict(cfg_c, num_layers=1, num_single_layers=0)
+    tp, cp = orc.init_mmdit_params(c1_t, seed=0, round_bf16=False), orc.init_mmdit_params(c1_c, seed=1, round_bf16=False, controlnet=True)
+    g = torch.Generator().manual_seed(0)
+    N1, T = 256, 512
+    lat, pe, pooled, hint = torch.randn(1, N1, 64, generator=g), torch.randn(1, T, 4096, generator=g), torch.randn(1, 768, generator=g), torch.randn(1, N1, 128, generator=g)
+    sig = orc.flow_sigmas(2, orc.calculate_shift(N1, 256, 4096, 0.5, 1.15))
+    mask = (torch.rand(1, N1, 1, generator=g) > 0.5).float()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.denoise_loop(tp, c1_t, cp, c1_c, lat, pe, pooled, [hint], [mask], sig, orc.latent_image_ids(32, 32), torch.zeros(T, 3), 3.5)
+        c1_s = time.perf_counter() - t0
+    del tp, cp
+    # ---- (2) C2 blocks
+    N = (H // 16) * (W // 16)
     small = dict(cfg_t, num_layers=1, num_single_layers=1)
     p = orc.init_mmdit_params(small, seed=0, round_bf16=False)
-    g = torch.Generator().manual_seed(0)
     h, e = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g)
     temb = torch.randn(1, d, generator=g)
     rope = orc.rope_table(torch.cat([torch.zeros(T, 3), orc.latent_image_ids(2 * (H // 16), 2 * (W // 16))]))
@@ -200,10 +249,13 @@ def cpu_baseline(cfg_t, H, W, steps, lines, cfg_c, budget_s=12.0):
     n_double = cfg_t["num_layers"] + lines * cfg_c["num_layers"]
     n_single = cfg_t["num_single_layers"] + lines * cfg_c["num_single_layers"]
     sec_per_image = steps * (n_double * td + n_single * ts)
-    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 torch-CPU: {nd} double + {ns} single MMDiT blocks at S={T+N}, d={d} "
-                      f"({td:.2f}s / {ts:.2f}s each), extrapolated to {steps} steps x ({n_double} double + {n_single} single) blocks; "
-                      "embedders, zero-linears and VAE decode not included"}
+    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+            "config1_full_run_s": round(c1_s, 2),
+            "sample": f"oracle fp32 torch-CPU on {cores} threads. (1) BASELINE config 1 run in full through oracle.denoise_loop: 256x256, "
+                      f"2 steps, S=768, d={d}, one masked text line, depth 2+2 / tower 1+0 (reduced, stated): {c1_s:.1f} s. "
+                      f"(2) value: {nd} double + {ns} single MMDiT blocks at the C2 sequence S={T+N} ({td:.2f}s / {ts:.2f}s each), "
+                      f"extrapolated to {steps} steps x ({n_double} double + {n_single} single) blocks (the reference evaluates all "
+                      f"{cfg_c['num_layers']} tower blocks); embedders, zero-linears and VAE decode not included"}
 
 
 def main():
@@ -225,17 +277,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # RCCL over xGMI is the path. If the communicator cannot be created the run FAILS (non-zero exit): a silent gloo
+            # fallback would publish a number for a different transport. RT_DIST_BACKEND=gloo asks for the host transport
+            # explicitly (rehearsals on a box with fewer GPUs than ranks, CPU tests).
             try:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
                 probe = torch.zeros(1, device=dev)
                 dist.all_reduce(probe)                     # forces communicator creation now, not inside the timed region
                 torch.cuda.synchronize()
-            except Exception as e:                        # RCCL unusable on this node: the path has ONE broadcast, gloo can carry it
-                print(f"[bench] RCCL init failed on rank {rank} ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            except Exception as e:
+                print(f"[bench] RCCL init failed on rank {rank} ({type(e).__name__}: {e}). Not falling back: set RT_DIST_BACKEND=gloo "
+                      "to run the broadcast over host memory on purpose.", file=sys.stderr, flush=True)
+                raise SystemExit(3)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -269,38 +322,52 @@ def main():
                                   text_encoder_2=None, tokenizer_2=None, transformer=transformer, controlnet=controlnet)
     pipe.set_progress_bar_config(disable=True)
 
-    H, W, Bl = args.height, args.width, args.batch_per_gpu
+    H, W = args.height, args.width
+    strong = args.global_batch > 0
+    G = args.global_batch if strong else world * args.batch_per_gpu           # images per pass over all ranks
+    if G < world:
+        raise SystemExit(f"--global-batch {G} < {world} ranks: every rank needs at least one image")
+    lo, hi = rdist.shard_range(G, rank, world)
+    Bl = hi - lo                                                              # this rank's share
     N = (H // 16) * (W // 16)
-    # ---- conditioning: rank 0 builds it, ONE broadcast; text encoders are outside the timed region
-    spec = [("prompt_embeds", (1, 512, 4096)), ("pooled", (1, 768))] + [(f"hint{i}", (1, N, 128)) for i in range(args.text_lines)] + \
-           [(f"mask{i}", (N,)) for i in range(args.text_lines)]
+    Gc = 1 if args.shared_prompt else G                                       # leading dim of the conditioning on the wire
+    # ---- conditioning: rank 0 builds it for the WHOLE batch (one prompt, hint and regional mask per image unless
+    #      --shared-prompt), ONE broadcast, every rank keeps its rows; text encoders are outside the timed region
+    spec = [("prompt_embeds", (Gc, 512, 4096)), ("pooled", (Gc, 768))] + [(f"hint{i}", (Gc, N, 128)) for i in range(args.text_lines)] + \
+           [(f"mask{i}", (Gc, N)) for i in range(args.text_lines)]
     cond = None
     if rank == 0:
         g = torch.Generator().manual_seed(1)
-        pe = torch.randn(1, 512, 4096, generator=g)
-        pooled = torch.randn(1, 768, generator=g)
+        pe = torch.randn(Gc, 512, 4096, generator=g)
+        pooled = torch.randn(Gc, 768, generator=g)
         g2 = torch.Generator().manual_seed(2)
-        hints = [torch.randn(1, N, 128, generator=g2) for _ in range(args.text_lines)]
-        _, _, mask_img = synthetic_glyph_hint(H, W)
-        m = pipe._region_masks([mask_img] * args.text_lines, "cpu", torch.float32)
-        cond = rdist.Conditioning(pe, pooled, hints, [t.reshape(-1) for t in m])
+        hints = [torch.randn(Gc, N, 128, generator=g2) for _ in range(args.text_lines)]
+        masks = []
+        for _ in range(args.text_lines):
+            per = []
+            for s_i in range(Gc):                                               # a glyph box per image: same size, shifted position
+                _, _, mask_img = synthetic_glyph_hint(H, W, shift=s_i)
+                per.append(pipe._region_masks([mask_img], "cpu", torch.float32)[0].reshape(-1))
+            masks.append(torch.stack(per))
+        cond = rdist.Conditioning(pe.to(bf16).float(), pooled.to(bf16).float(), [h.to(bf16).float() for h in hints], masks)
     if world > 1:
         cond = rdist.broadcast_conditioning(cond, spec, dev, staging_device=("cpu" if backend == "gloo" else None))
     else:
         cond = rdist.Conditioning(cond.prompt_embeds.to(dev, bf16), cond.pooled.to(dev, bf16), [h.to(dev, bf16) for h in cond.hints],
                                   [m.to(dev) for m in cond.masks])
-    pe = cond.prompt_embeds.expand(Bl, -1, -1).contiguous()
-    pooled = cond.pooled.expand(Bl, -1).contiguous()
-    hints = [h.expand(Bl, -1, -1).contiguous() for h in cond.hints]
+    mine = cond.shard(lo, hi)
+    pe = mine.prompt_embeds.contiguous()
+    pooled = mine.pooled.contiguous()
+    hints = [h.contiguous() for h in mine.hints]
+    masks_l = [m.contiguous() for m in mine.masks]                             # per line [Bl, N]
 
-    lo, hi = rdist.shard_range(world * Bl, rank, world)
     marks = []                                   # per timed pass: (start, loop end, decode end) events
 
     def one_pass(pass_idx):
-        ids = [pass_idx * world * Bl + s for s in range(lo, hi)]
+        ids = [pass_idx * G + s for s in range(lo, hi)]
         noise = rdist.sample_noise(ids, (16, 2 * (H // 16), 2 * (W // 16)), 42, bf16, dev)
         lat = pipe._pack_latents(noise, Bl, 16, 2 * (H // 16), 2 * (W // 16))
-        return run_image(pipe, lat, pe, pooled, hints, cond.masks, H, W, args.inference_steps, marks if pass_idx >= 0 else None)
+        return run_image(pipe, lat, pe, pooled, hints, masks_l, H, W, args.inference_steps, marks if pass_idx >= 0 else None)
 
     def barrier():
         if world > 1:
@@ -323,9 +390,12 @@ def main():
     timed_marks = marks[: args.steps]
     loop_ms = sorted(e[0].elapsed_time(e[1]) for e in timed_marks)[len(timed_marks) // 2] if timed_marks else None
     dec_ms = sorted(e[1].elapsed_time(e[2]) for e in timed_marks)[len(timed_marks) // 2] if timed_marks else None
-    images = world * Bl * args.steps
+    images = G * args.steps                                                   # all ranks, all timed passes
     value = images / elapsed
-    fl_img = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c)
+    n_tower = tower_blocks_read(cfg_t, cfg_c)
+    fl_img = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c, tower_blocks=n_tower)   # EXECUTED work
+    fl_img_ref = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c)                    # the reference's count
+    e2e_peak = 5.0e15 if args.precision == "fp8" else 2.5e15                    # dense MFMA peak of the dtype the projections run in
 
     roofline = None
     if rank == 0 and not args.no_roofline_pass:
@@ -342,7 +412,8 @@ def main():
                     "traffic": pmc_traffic_bytes(tkey) if tkey else None, "kernel": kname, "launches": n_launch,
                     "avg_launch_us": round(sec / n_launch * 1e6, 2), "avg_gflop_per_launch": round(fl / n_launch / 1e9, 2),
                     "e2e_tflops_per_gpu": round(fl_img * Bl * args.steps / elapsed / 1e12, 1),
-                    "e2e_frac": round(fl_img * Bl * args.steps / elapsed / 2.5e15, 4)}
+                    "e2e_frac": round(fl_img * Bl * args.steps / elapsed / e2e_peak, 4), "e2e_peak_tflops": e2e_peak / 1e12,
+                    "e2e_pflop_per_image_executed": round(fl_img / 1e15, 4), "e2e_pflop_per_image_reference": round(fl_img_ref / 1e15, 4)}
         na, fla, seca = gt.attention_result()
         if na:
             pk = 2500.0 if args.precision != "fp8" else 5000.0
@@ -364,12 +435,13 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "sec_per_image": round(elapsed / (args.steps * Bl), 4),
             "loop_only_ms_per_step": None if loop_ms is None else round(loop_ms, 2),          # rank 0, median over the timed passes
             "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8-ln": "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16",
                       "fp8": "fp8 (e4m3 block projections and attention; bf16 storage, fp32 residual stream)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
-                                   f"{args.text_lines} text line(s), batch {Bl}/GPU, denoise loop + VAE decode to uint8, random-init weights",
-                       "global_batch": world * Bl, "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},
+                                   f"{args.text_lines} text line(s), batch {Bl}/GPU on rank 0, denoise loop + VAE decode to uint8, random-init weights; "
+                                   f"tower blocks evaluated {n_tower} of {cfg_c['num_layers']} (the last sample is never read, Q5)",
+                       "global_batch": G, "conditioning": "shared prompt/hint/mask" if args.shared_prompt else "one prompt, hint and mask per image", "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.depth_scale != 1.0:
@@ -395,7 +467,7 @@ def run_image(pipe, latents, pe, pooled, hints, rowscales, H, W, steps, marks=No
     text_ids = torch.zeros(pe.shape[1], 3, device=dev, dtype=latents.dtype)
     image_ids = pipe._prepare_latent_image_ids(B, h2, w2, dev, latents.dtype)
     pipe._guidance_scale, pipe._joint_attention_kwargs, pipe._interrupt = 3.5, None, False
-    masks = [m.reshape(1, -1, 1) for m in rowscales]
+    masks = [m.reshape(m.shape[0], -1, 1) for m in rowscales]          # per line [B, N, 1] (one regional mask per image)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
     if ev:
         ev[0].record()

@@ -44,7 +44,7 @@ int rt_abi_version(void);
  *   if n >= gelu_from:        v = gelu_tanh(v)                      (A.1 step 7 / A.2 act_mlp)
  *   if gate:                  v *= gate[(m / rows_per_batch) * gate_ld + n]   (adaLN-Zero gates)
  *   v *= alpha                                                      (CN:395 conditioning_scale)
- *   if rowscale:              v *= rowscale[m % rows_per_batch]     (PIPE:1062 regional mask)
+ *   if rowscale:              v *= rowscale[batch_index * stride_rowscale + m % rows_per_batch]   (PIPE:1062 regional mask)
  *   if res:                   v += res[m*ldr + n]                   (residual stream)
  *   if add2:                  v += add2[m*ld2 + n]                  (A.3 ControlNet injection)
  *   C[m*ldc + n] = v   (bf16, or fp32 when out_f32)
@@ -76,6 +76,8 @@ typedef struct rt_gemm_group {
    *   acc[m][n] * a_scale[b*M + m] * w_scale[n]      (either pointer may be NULL = 1.0) */
   const float* a_scale; /* f32 [batch*M], one per activation row (rt_layernorm_modulate_fp8 / rt_quantize_rows_fp8) */
   const float* w_scale; /* f32 [N], one per output channel (rt_quantize_rows_fp8 on the weight rows)              */
+  int64_t stride_rowscale; /* elements between the rowscale vectors of consecutive batch entries; 0 = one vector shared by the
+                            * batch (the reference's one mask per text line); > 0: a mask per image of a sharded batch        */
 } rt_gemm_group;
 
 int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
@@ -134,11 +136,22 @@ int rt_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t stride_b, int64_t q_off, i
 
 /* Joint (non-causal, unmasked) attention, softmax(QKᵀ·scale)V, Dh = 128, flash-style on MFMA
  * (A.1 step 6; torch SDPA in the reference). q/k/v/o are bf16 with a common row stride ld
- * (elements) and per-batch stride; head h lives at column h*128. o may alias q (each workgroup
- * reads only the q rows it later overwrites). */
+ * (elements) and per-batch stride; head h lives at column h*128. o may alias q (the query rows of
+ * a 128-row block are overwritten only after every workgroup that reads them has finished).
+ *
+ * `ws` (optional, 256-byte aligned, rt_attention_ws_bytes(B,S,H) bytes): workspace of the key-split
+ * tail. When (heads x query blocks) does not fill a whole number of rounds of the chip's workgroup
+ * slots, the key tiles of the last partial round are dealt evenly over all slots and the partial
+ * (max, sum, O) triples are combined in-kernel by the last arriver, in a fixed order (bitwise
+ * reproducible; every batch entry is cut identically, so results do not depend on B). The first
+ * B*H*ceil(S/128) int32 of ws are ticket counters: zero them ONCE after allocation; the kernel
+ * leaves them zero. ws == NULL runs every block as one full-length workgroup.
+ * rt_attention_ws_bytes returns 0 when nothing would be split for this shape on this device. */
+int64_t rt_attention_ws_bytes(int32_t B, int32_t S, int32_t H);
 int rt_attention_fwd(const void* q, const void* k, const void* v, void* o,
                      int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
-                     int32_t B, int32_t S, int32_t H, float scale, void* stream);
+                     int32_t B, int32_t S, int32_t H, float scale,
+                     void* ws, int64_t ws_bytes, void* stream);
 
 /* BASELINE config 5, "CDNA4 fp8 MFMA attention": the same joint attention with e4m3 q, k, v and softmax numerators on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 scores, statistics and accumulators; bf16 output). Static quantisation: q and k

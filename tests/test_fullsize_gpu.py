@@ -211,3 +211,106 @@ def test_kernels_are_bitwise_reproducible_at_c2_shapes(gpu):
             o.zero_()
             ops.linear(a, w, o)
             assert torch.equal(o, r0)
+
+
+# ------------------------------------------------------------------------------------------- attention: key-split tail
+def _sdpa_rows(qkv, d, h, rows):
+    """fp32 softmax(q k^T / sqrt(128)) v of the given query rows of head h, on the device."""
+    q = qkv[0, rows, h * 128 : (h + 1) * 128].float()
+    k = qkv[0, :, d + h * 128 : d + (h + 1) * 128].float()
+    v = qkv[0, :, 2 * d + h * 128 : 2 * d + (h + 1) * 128].float()
+    return torch.softmax(q @ k.t() / 128 ** 0.5, dim=-1) @ v
+
+
+@pytest.mark.parametrize("S", [4608, 4500])
+def test_attention_key_split_tail(gpu, S):
+    """C2 shape (and a ragged neighbour): 864 query blocks on 512 workgroup slots. The blocks of the partial round are cut
+    along the keys and recombined in-kernel (rt_attention_fwd with a workspace). Against the unsplit launch and an fp32
+    reference; bitwise repeatable; independent of the batch size; with one key that dominates a query row placed in either
+    lane half of the score tile and on either side of a cut (forces the rescale branch and the combine's re-weighting)."""
+    import reptext_amd.ops as ops
+    from reptext_amd import native
+
+    H, d = 24, 3072
+    assert native.load().rt_attention_ws_bytes(1, S, H) > 0          # this shape does split on a 256-CU part
+    g = torch.Generator(device=gpu).manual_seed(S)
+    qkv = (torch.randn(1, S, 3 * d, device=gpu, generator=g) * 1.2).to(torch.bfloat16)
+    # rows whose score against one key is ~100 log2 units above the rest; heads 20 and 23 are split blocks of their XCD group
+    spikes = [(3, 77, 1038), (4, 200, 1070), (20, 4400, 14), (21, 4433, 3000), (23, 4490, S - 70)]   # one per head
+    for h, row, key in spikes:
+        qkv[0, row, h * 128 : (h + 1) * 128] = 1.0
+        qkv[0, key, d + h * 128 : d + (h + 1) * 128] = 8.0
+    q, k, v = qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :]
+    o_split, o_full = torch.empty(1, S, d, device=gpu, dtype=torch.bfloat16), torch.empty(1, S, d, device=gpu, dtype=torch.bfloat16)
+    ops.attention(q, k, v, o_split, H)
+    ops.attention(q, k, v, o_full, H, split=False)
+    assert torch.isfinite(o_split.float()).all() and torch.isfinite(o_full.float()).all()
+    assert rel_l2(o_split.float(), o_full.float()) < 1.5e-3            # two bf16 roundings of the same fp32 values
+    frac_equal = float((o_split == o_full).float().mean())
+    assert frac_equal > 0.55                                           # the 512 full-length blocks are bit-identical
+    for h, row, key in spikes:
+        rows = torch.arange(max(0, row - 4), min(S, row + 4), device=gpu)
+        ref = _sdpa_rows(qkv, d, h, rows)
+        for o in (o_split, o_full):
+            assert rel_l2(o[0, rows, h * 128 : (h + 1) * 128].float(), ref) < 5e-3
+        # the spiked row is (almost exactly) the value row of its dominant key
+        assert float((o_split[0, row, h * 128 : (h + 1) * 128].float() - qkv[0, key, 2 * d + h * 128 : 2 * d + (h + 1) * 128].float()).abs().max()) < 0.05
+    rows = torch.arange(4000, 4016, device=gpu)
+    assert rel_l2(o_split[0, rows, 5 * 128 : 6 * 128].float(), _sdpa_rows(qkv, d, 5, rows)) < 5e-3
+    # bitwise repeatable (the combine runs in run order, not arrival order) and the ticket counters return to zero
+    for _ in range(4):
+        o2 = torch.zeros_like(o_split)
+        ops.attention(q, k, v, o2, H)
+        assert torch.equal(o2, o_split)
+    # every batch entry is cut identically: entry b of a batch equals the batch-1 launch, bit for bit
+    qkv3 = torch.cat([qkv, qkv.flip(1), qkv], dim=0).contiguous()
+    o3 = torch.empty(3, S, d, device=gpu, dtype=torch.bfloat16)
+    ops.attention(qkv3[..., :d], qkv3[..., d : 2 * d], qkv3[..., 2 * d :], o3, H)
+    assert torch.equal(o3[0], o_split[0]) and torch.equal(o3[2], o_split[0])
+    # in place over q
+    qkv_c = qkv.clone()
+    ops.attention(qkv_c[..., :d], qkv_c[..., d : 2 * d], qkv_c[..., 2 * d :], qkv_c[..., :d], H)
+    assert torch.equal(qkv_c[..., :d], o_split)
+
+
+def test_attention_and_gemm_properties_at_c5_shape(gpu):
+    """BASELINE config 5 shape (1536^2: S = 9728, H = 24) on the bf16 kernels: constant-V, key permutation, bitwise repeat,
+    a 16-row fp32 spot check; the two GEMM shapes of the single block at M = 9728 through exact scaling + a row spot check."""
+    import reptext_amd.ops as ops
+
+    B, S, H = 1, 9728, 24
+    d = H * 128
+    g = torch.Generator(device=gpu).manual_seed(9)
+    qkv = torch.randn(B, S, 3 * d, device=gpu, generator=g).to(torch.bfloat16)
+    out = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
+    ops.attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], out, H)
+    rows = torch.arange(9000, 9016, device=gpu)
+    assert rel_l2(out[0, rows, 11 * 128 : 12 * 128].float(), _sdpa_rows(qkv, d, 11, rows)) < 5e-3
+    out2 = torch.zeros_like(out)
+    ops.attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], out2, H)
+    assert torch.equal(out, out2)
+    perm = torch.randperm(S, device=gpu, generator=g)
+    qkv_p = qkv.clone()
+    qkv_p[:, :, d:] = qkv[:, perm, d:]
+    out_p = torch.empty_like(out)
+    ops.attention(qkv_p[..., :d], qkv_p[..., d : 2 * d], qkv_p[..., 2 * d :], out_p, H)
+    assert rel_l2(out_p.float(), out.float()) < 4e-3
+    vrow = torch.randn(d, device=gpu, generator=g).to(torch.bfloat16)
+    qkv_p[:, :, 2 * d :] = vrow
+    ops.attention(qkv_p[..., :d], qkv_p[..., d : 2 * d], qkv_p[..., 2 * d :], out_p, H)
+    assert rel_l2(out_p.float(), vrow.float().expand(B, S, d)) < 4e-3
+    del qkv_p, out_p, out2
+    for (M, N, K) in [(9728, 21504, 3072), (9728, 3072, 15360)]:
+        a = torch.randn(M, K, device=gpu, generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=gpu, generator=g) * 0.02).to(torch.bfloat16)
+        o = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+        ops.linear(a, w, o)
+        o_again = torch.zeros_like(o)
+        ops.linear(a, w, o_again)
+        assert torch.equal(o, o_again)
+        o4 = torch.empty_like(o)
+        ops.linear(a * 4, w, o4)                                        # exact scaling by a power of two
+        assert torch.equal(o4.float(), o.float() * 4)
+        rows = torch.tensor([0, 255, 256, 4863, 9000, M - 1], device=gpu)
+        ref = a[rows].float() @ w.float().t()
+        assert rel_l2(o[rows].float(), ref) < 3e-3

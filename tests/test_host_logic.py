@@ -233,3 +233,90 @@ def test_t5_relative_position_bucket_matches_transformers_cpu():
     rel = torch.arange(-700, 700)[None, :] - torch.arange(0, 5)[:, None]
     for nb, md in ((32, 128), (64, 256), (16, 64)):
         assert torch.equal(t5_relative_position_bucket(rel, nb, md), T5Attention._relative_position_bucket(rel, True, nb, md))
+
+
+# ------------------------------------------------------------------------------------------- checkpoint formats
+def _fake_hub_cache(tmp_path, monkeypatch, repo_id, populate):
+    """<cache>/models--ORG--NAME/{refs/main, snapshots/<commit>/...}: the layout huggingface_hub leaves behind (offline)."""
+    cache = tmp_path / "hf_home" / "hub"
+    commit = "0123456789abcdef0123456789abcdef01234567"
+    snap = cache / ("models--" + repo_id.replace("/", "--")) / "snapshots" / commit
+    snap.mkdir(parents=True)
+    refs = snap.parent.parent / "refs"
+    refs.mkdir()
+    (refs / "main").write_text(commit)
+    populate(str(snap))
+    for env in ("HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE"):
+        monkeypatch.delenv(env, raising=False)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf_home"))
+    return str(snap)
+
+
+def test_hub_ids_resolve_through_the_local_hub_cache(tmp_path, monkeypatch):
+    """infer.py:30-31 passes hub ids. Offline they must resolve through $HF_HOME/hub/models--ORG--NAME/snapshots/<commit>,
+    and fail loudly (naming the paths tried) when no snapshot is cached."""
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.modules import resolve_model_path
+
+    cn = FluxControlNetModel(**SMALL_CN, device="cpu", dtype=torch.bfloat16)
+    cn.load_state_dict(orc.init_mmdit_params(SMALL_CN, 5, controlnet=True))
+    snap = _fake_hub_cache(tmp_path, monkeypatch, "Shakker-Labs/RepText", cn.save_pretrained)
+    assert resolve_model_path("Shakker-Labs/RepText") == snap
+    cn2 = FluxControlNetModel.from_pretrained("Shakker-Labs/RepText", torch_dtype=torch.bfloat16)       # infer.py:30, unchanged
+    for (k, a), (_, b) in zip(sorted(cn.state_dict().items()), sorted(cn2.state_dict().items())):
+        assert torch.equal(a, b), k
+    with pytest.raises(OSError, match="models--black-forest-labs--FLUX.1-dev"):
+        resolve_model_path("black-forest-labs/FLUX.1-dev")
+    assert resolve_model_path(snap) == snap                                                            # a directory stays a directory
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "elsewhere"))                                     # takes precedence over HF_HOME
+    with pytest.raises(OSError):
+        resolve_model_path("Shakker-Labs/RepText")
+
+
+def test_sharded_checkpoint_with_index_roundtrip(tmp_path):
+    """FLUX.1-dev's transformer ships as three shards + diffusion_pytorch_model.safetensors.index.json (NB:2116-2118)."""
+    import json
+
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    tr = FluxTransformer2DModel(**SMALL_T, device="cpu", dtype=torch.bfloat16)
+    tr.load_state_dict(orc.init_mmdit_params(SMALL_T, 7))
+    total = sum(v.numel() * 2 for v in tr.state_dict().values())
+    d = tmp_path / "tr"
+    tr.save_pretrained(str(d), max_shard_bytes=total // 2)                # greedy packing of whole tensors: 3 shards here
+    files = sorted(os.listdir(d))
+    shards = [f for f in files if f.endswith(".safetensors")]
+    assert len(shards) >= 3 and shards[0] == f"diffusion_pytorch_model-00001-of-{len(shards):05d}.safetensors"
+    idx = json.load(open(d / "diffusion_pytorch_model.safetensors.index.json"))
+    assert set(idx["weight_map"]) == set(tr.state_dict()) and idx["metadata"]["total_size"] == total
+    tr2 = FluxTransformer2DModel.from_pretrained(str(d), torch_dtype=torch.bfloat16)
+    for (k, a), (_, b) in zip(sorted(tr.state_dict().items()), sorted(tr2.state_dict().items())):
+        assert torch.equal(a, b), k
+    os.remove(d / shards[1])                                              # a shard the index names is missing: loud error
+    with pytest.raises(OSError, match="missing"):
+        FluxTransformer2DModel.from_pretrained(str(d), torch_dtype=torch.bfloat16)
+
+
+def test_pipeline_from_pretrained_reads_model_index(tmp_path, monkeypatch):
+    """infer.py:31-33: FluxControlNetPipeline.from_pretrained(<hub id>, controlnet=..., torch_dtype=...). model_index.json
+    decides which components exist; text encoders marked [null, null] stay None."""
+    import json
+
+    from reptext_amd.pipeline import FluxControlNetPipeline
+
+    pipe = _cpu_pipe()
+    pipe.transformer.load_state_dict(orc.init_mmdit_params(SMALL_T, 11))
+    pipe.vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vorc.init_vae_params(dict(vorc.FLUX_VAE_CFG, block_out_channels=(32, 32, 64, 64)), 2).items()})
+    snap = _fake_hub_cache(tmp_path, monkeypatch, "black-forest-labs/FLUX.1-dev", pipe.save_pretrained)
+    idx = json.load(open(os.path.join(snap, "model_index.json")))
+    assert idx["_class_name"] == "FluxControlNetPipeline" and idx["text_encoder"] == [None, None] and idx["transformer"][1] == "FluxTransformer2DModel"
+    p2 = FluxControlNetPipeline.from_pretrained("black-forest-labs/FLUX.1-dev", controlnet=pipe.controlnet, torch_dtype=torch.bfloat16)
+    assert p2.controlnet is pipe.controlnet and p2.text_encoder is None and p2.tokenizer_2 is None
+    assert dict(p2.scheduler.config) == dict(pipe.scheduler.config)
+    for (k, a), (_, b) in zip(sorted(pipe.transformer.state_dict().items()), sorted(p2.transformer.state_dict().items())):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(sorted(pipe.vae.state_dict().items()), sorted(p2.vae.state_dict().items())):
+        assert torch.equal(a, b), k
+    os.rename(os.path.join(snap, "vae"), os.path.join(snap, "vae_gone"))
+    with pytest.raises(OSError, match="vae"):
+        FluxControlNetPipeline.from_pretrained("black-forest-labs/FLUX.1-dev", controlnet=pipe.controlnet)

@@ -326,7 +326,7 @@ def test_call_with_pil_hints_matches_oracle_prelude(vae_pair, gpu):
                            torch.zeros(T, 3), 3.5)
     err = rel_l2(out.float().cpu(), ref)
     print(f"PIL-hint call (VAE-encoded hints, Q1/Q2 RNG order) latents rel-L2 {err:.3e}")
-    assert err < 3e-2
+    assert err < 4e-3          # measured 1.3e-3 (hint latents come from the bf16 VAE encoder: 1e-2 on the hints, 1e-3 on the latents)
 
 
 def test_vae_is_bitwise_reproducible(vae_pair, gpu):

@@ -57,7 +57,7 @@ int main() {
     hipMalloc(&dq, qkv.size() * 2); hipMalloc(&dout, o.size() * 2);
     hipMemcpy(dq, qkv.data(), qkv.size() * 2, hipMemcpyHostToDevice);
     const uint16_t* base = (const uint16_t*)dq;
-    const int rc = rt_attention_fwd(base, base + D, base + 2 * D, dout, 3 * D, (int64_t)S * 3 * D, D, (int64_t)S * D, 1, S, H, 1.f / sqrtf((float)D), nullptr);
+    const int rc = rt_attention_fwd(base, base + D, base + 2 * D, dout, 3 * D, (int64_t)S * 3 * D, D, (int64_t)S * D, 1, S, H, 1.f / sqrtf((float)D), nullptr, 0, nullptr);
     hipDeviceSynchronize();
     hipMemcpy(o.data(), dout, o.size() * 2, hipMemcpyDeviceToHost);
     double worst = 0;
