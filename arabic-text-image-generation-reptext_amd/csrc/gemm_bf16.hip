@@ -164,113 +164,8 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
   }
 }
 
-__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_simple_kernel(const Launch L) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // ---- which problem / tile is this workgroup? (scalar)
-  // The by-value Launch is indexed dynamically; read it through the kernarg segment pointer (scalar loads)
-  // so the compiler does not copy the struct to scratch.
-  typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
-  LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  (void)L;
-  int gi = 0;
-#pragma unroll
-  for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
-    if (i < Lp->ngroups && (int)blockIdx.x >= Lp->grp[i].tile_begin) gi = i;
-#if defined(__HIP_DEVICE_COMPILE__)
-  const GroupDev G = Lp->grp[gi];      // scalar loads into SGPRs
-#else
-  const GroupDev G = L.grp[0];         // host pass only parses this body
-#endif
-  const rt_gemm_group& g = G.g;
-  int t = (int)blockIdx.x - G.tile_begin;
-  const int tiles_per_batch = G.tiles_m * G.tiles_n;
-  const int bidx = t / tiles_per_batch;
-  t -= bidx * tiles_per_batch;
-  const int tn = t / G.tiles_m;
-  const int tm = t - tn * G.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  // ---- staging addresses: wave w stages rows [32w, 32w+32) of each operand, 4 pieces of 8 rows.
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)bidx * g.strideA;
-  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
-  const bf16_t* srcA[4];
-  const bf16_t* srcW[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = wave * 32 + p * 8 + (lane >> 3);
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch
-    const int am = min(m0 + row, g.M - 1);             // clamp: tail rows read valid memory, never stored
-    const int wr = min(n0 + row, g.N - 1);
-    srcA[p] = Ab + (int64_t)am * g.lda + lc * 8;
-    srcW[p] = Wb + (int64_t)wr * g.ldw + lc * 8;
-  }
-  const int stage_off = wave * 32 * 128;               // byte offset of this wave's rows inside a tile
-
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * BUF_BYTES + stage_off;
-    const int koff = kt * BK;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(srcA[p] + koff), LDS_PTR(base + p * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(srcW[p] + koff), LDS_PTR(base + TILE_BYTES + p * 1024), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment read offsets (bytes inside a tile); identical swizzle for both operands.
-  const int l15 = lane & 15;
-  const int sw = (lane >> 1) & 7;                       // ((row>>1)&7) with row ≡ l15 (mod 16)
-  const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
-  const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
-  const int a_base = wm * 128 * 128;                    // activation rows of this wave (bytes)
-  const int w_base = TILE_BYTES + wn * 64 * 128;        // weight rows of this wave
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / BK;
-  stage(0, 0);
-  rt_dma_barrier();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* tb = smem + cur * BUF_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int rd = kk ? rd1 : rd0;
-      bf16x8 wf[4], af[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(tb + w_base + j * 2048 + rd);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tb + a_base + i * 2048 + rd);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    rt_dma_barrier();  // drains every wave's LDS-DMA (vmcnt(0)), then orders buffer reuse
-  }
-
-  // ---- epilogue: lane owns row m = ... + l15 and columns n = ... + 4*(lane>>4) .. +3 of each fragment
-  const int mrow = m0 + wm * 128 + l15;
-  const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
-  if (g.out_f32) epilogue_tile<true>(g, bidx, mrow, ncol, acc);
-  else epilogue_tile<false>(g, bidx, mrow, ncol, acc);
-}
-
-
 // ---------------------------------------------------------------------------------------------------
-// Ping-pong variant (default). Same tile, LDS image and MFMA mapping as the simple kernel, different schedule:
+// gemm_pp_kernel: the ping-pong schedule.
 //   * a K-tile is consumed in 4 phases of 16 MFMAs, one quadrant of the wave's 128x64 output each, in the order
 //     (a0,b0) (a0,b1) (a1,b1) (a1,b0) so only 12+4+8+0 fragment reads are needed per K-tile;
 //   * waves 4-7 run one barrier behind waves 0-3, so of the two waves that share a SIMD one is in its MFMA cluster
@@ -474,8 +369,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
 
   const int mrow = m0 + wm * 128 + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
+#ifdef RT_GEMM_ABL_NOEPI     // timing-only build (tools): keep the accumulators alive, skip the epilogue
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.f) reinterpret_cast<float*>(g.C)[0] = sacc;
+  }
+#else
   if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);
   else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc, G.wide_store != 0);
+#endif
 }
 
 }  // namespace
@@ -512,18 +418,15 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     L.grp[i].tile_begin = total;
     total += L.grp[i].tiles_m * L.grp[i].tiles_n * g.batch;
   }
-  static int variant = -1;   // RT_GEMM_VARIANT=simple selects the 2-phase reference schedule (A/B and debugging; bf16 only)
-  if (variant < 0) {
-    const char* v = getenv("RT_GEMM_VARIANT");
-    variant = (v && v[0] == 's') ? 0 : 1;
-    for (const void* f : {reinterpret_cast<const void*>(gemm_pp_kernel<false>), reinterpret_cast<const void*>(gemm_pp_kernel<true>),
-                          reinterpret_cast<const void*>(gemm_bf16_simple_kernel)}) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void* f : {reinterpret_cast<const void*>(gemm_pp_kernel<false>), reinterpret_cast<const void*>(gemm_pp_kernel<true>)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) return (int)e;
     }
+    attr_done = true;
   }
   if (fp8) hipLaunchKernelGGL(gemm_pp_kernel<true>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
-  else if (variant == 0) hipLaunchKernelGGL(gemm_bf16_simple_kernel, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
   else hipLaunchKernelGGL(gemm_pp_kernel<false>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
   return rt_hip_status();
 }

@@ -6,7 +6,10 @@ without `cv2` can feed `FluxControlNetPipeline.__call__`. This runs once per ima
 
 `canny_edges` follows the algorithm OpenCV documents for `cv::Canny(image, 50, 100)` with its defaults (3x3 Sobel with
 replicated borders, L1 gradient magnitude, non-maximum suppression over four direction sectors split at tan 22.5° and
-tan 67.5°, hysteresis with 8-connectivity). Parity with OpenCV is UNPINNED: cv2 is not installed here and the reference holds
+tan 67.5°, hysteresis with 8-connectivity). A 3-channel input is NOT converted to gray (infer.py:16-22 hands cv2.Canny the
+3-channel glyph image): as cv::Canny does for cn > 1, the Sobel derivatives are taken per channel and, per pixel, the
+channel with the largest |dx| + |dy| supplies (dx, dy) — so coloured glyphs (text_color_list is a user knob) give the same
+contour as white ones, which a luma conversion would not (pure blue (0,0,128) has luma 15: gradient 60, below both thresholds). Parity with OpenCV is UNPINNED: cv2 is not installed here and the reference holds
 no edge-map fixture; the tests pin the properties the downstream path relies on (closed one-pixel contours around glyph
 strokes, threshold behaviour, shape/dtype, inversion).
 """
@@ -38,12 +41,23 @@ def _sobel3(gray: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def canny_edges(image: np.ndarray, low_threshold: float = 50, high_threshold: float = 100) -> np.ndarray:
-    """uint8 [H, W] (or [H, W, 3], converted to gray first) -> uint8 [H, W] edge map with values {0, 255}."""
-    gray = rgb_to_gray_u8(image) if image.ndim == 3 else image.astype(np.uint8)
+    """uint8 [H, W] or [H, W, C] -> uint8 [H, W] edge map with values {0, 255}. Multi-channel: per pixel the channel with the
+    largest L1 gradient magnitude supplies the gradient (cv::Canny with cn > 1); no gray conversion."""
     if low_threshold > high_threshold:
         low_threshold, high_threshold = high_threshold, low_threshold
-    H, W = gray.shape
-    dx, dy = _sobel3(gray)
+    if image.ndim == 3:
+        H, W, cn = image.shape
+        dx = np.zeros([H, W], dtype=np.int32)
+        dy = np.zeros([H, W], dtype=np.int32)
+        best = np.full([H, W], -1, dtype=np.int32)
+        for c in range(cn):                                          # first channel wins ties, as the strict '>' of cv::Canny's loop
+            cx, cy = _sobel3(image[..., c].astype(np.uint8))
+            m_c = np.abs(cx) + np.abs(cy)
+            take = m_c > best
+            dx, dy, best = np.where(take, cx, dx), np.where(take, cy, dy), np.where(take, m_c, best)
+    else:
+        H, W = image.shape
+        dx, dy = _sobel3(image.astype(np.uint8))
     mag = np.abs(dx) + np.abs(dy)                                   # L1 norm (L2gradient=False)
     m = np.pad(mag, 1, mode="constant")                             # zero border: nothing outside the image is a maximum
     c = m[1:-1, 1:-1]

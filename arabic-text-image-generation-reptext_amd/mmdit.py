@@ -31,6 +31,22 @@ BF16, F32 = torch.bfloat16, torch.float32
 # +1.9 % time per image (the GEMM epilogue and LayerNorm kernels take either dtype). RT_RESIDUAL_F32=0 selects bf16.
 RESIDUAL_F32 = os.environ.get("RT_RESIDUAL_F32", "1") == "1"
 
+# The reference's bf16 run rounds the SCALARS that feed the sinusoidal embeddings: PIPE:1025 casts t to the latents' dtype,
+# PIPE:1048/1094 divide by 1000 in bf16 and CN:282-284 multiply by 1000 in bf16 again — t = 967.3 enters the embedding as 968,
+# guidance 3.5 as 3504. The default here (and in the oracle) is the exact fp32 value, i.e. the fp32 CPU run the parity target
+# names; `reference_bf16_scalars(True)` (pipelines: `pipe.reference_bf16_scalars = True`) reproduces the bf16 run's values.
+REF_BF16_SCALARS = False
+
+
+def reference_bf16_scalars(on: bool = True) -> None:
+    global REF_BF16_SCALARS
+    REF_BF16_SCALARS = bool(on)
+
+
+def bf16_round_trip_x1000(v: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor holding what CN:282-284 computes from a model-scale scalar in a bf16 run: bf16(bf16(v) * 1000)."""
+    return (v.to(torch.bfloat16) * 1000).to(torch.float32)
+
 
 @dataclass
 class DoublePlan:

@@ -519,6 +519,18 @@ class FluxControlNetPipeline:
             return (image,)
         return FluxPipelineOutput(images=image)
 
+    reference_bf16_scalars = False     # True: round t, t/1000 and guidance to bf16 where the reference's bf16 run does (mmdit.py)
+
+    def _model_timestep(self, t: float) -> float:
+        """The value the models receive as `timestep` (PIPE:1025,1048: t.to(dtype) / 1000). fp32-exact by default; under
+        `reference_bf16_scalars` the bf16 run's value bf16(bf16(t) / 1000)."""
+        from . import mmdit
+
+        mmdit.reference_bf16_scalars(self.reference_bf16_scalars)
+        if not self.reference_bf16_scalars:
+            return t / 1000.0
+        return float((torch.tensor(t, dtype=torch.float32).to(torch.bfloat16) / 1000).to(torch.float32))
+
     # ------------------------------------------------------------------ hot loop (PIPE:1016-1130)
     def _denoise(self, latents, prompt_embeds, pooled, text_ids, image_ids, timesteps, hints, masks, guidance_scale,
                  cn_scale, cn_steps, control_mode, callback, callback_inputs, num_inference_steps):
@@ -530,7 +542,7 @@ class FluxControlNetPipeline:
         rowscales = [m.to(torch.float32).reshape(-1).contiguous() if m.shape[0] == 1 else m.to(torch.float32).reshape(m.shape[0], -1).contiguous() for m in masks]
         num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
         # adaLN vectors of every block for every step, once per image (timesteps/guidance/pooled are loop-invariant inputs)
-        model_ts = [t / 1000.0 for t in tvals]
+        model_ts = [self._model_timestep(t) for t in tvals]
         tab_t = self.transformer.build_modulation_table(model_ts, guidance, pooled)
         fused_cn = isinstance(self.controlnet, FluxControlNetModel) and len(hints) > 0
         tab_c = self.controlnet.build_modulation_table(model_ts[: max(0, min(len(model_ts), cn_steps))], guidance, pooled) if fused_cn and cn_steps > 0 else None
@@ -577,7 +589,7 @@ class FluxControlNetPipeline:
             for i, t in enumerate(tvals):
                 if self.interrupt:
                     continue
-                timestep = torch.full((B,), t / 1000.0, device=device, dtype=torch.float32)      # PIPE:1025,1048 (Q4)
+                timestep = torch.full((B,), self._model_timestep(t), device=device, dtype=torch.float32)      # PIPE:1025,1048 (Q4)
                 merged = merged_single = None
                 events = None
                 if overlap and i < cn_steps:

@@ -229,7 +229,7 @@ class FluxControlNetPipeline(_BasePipeline):
         # one regional mask per text line, shared by the batch ([1,N,1], the reference's form) or one per image ([B,N,1])
         rowscales = [m.to(torch.float32).reshape(-1).contiguous() if m.shape[0] == 1 else m.to(torch.float32).reshape(m.shape[0], -1).contiguous() for m in masks]
         num_warmup = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
-        model_ts = [t / 1000.0 for t in tvals]
+        model_ts = [self._model_timestep(t) for t in tvals]
         g_tab = guidance if guidance is None or pooled.shape[0] == B else guidance.expand(pooled.shape[0]).contiguous()
         tab_t = self.transformer.build_modulation_table(model_ts, g_tab, pooled)
         n_cn = max(0, min(len(model_ts), cn_steps))
@@ -260,7 +260,7 @@ class FluxControlNetPipeline(_BasePipeline):
             for i, t in enumerate(tvals):
                 if self.interrupt:
                     continue
-                timestep = torch.full((B,), t / 1000.0, device=device, dtype=torch.float32)
+                timestep = torch.full((B,), self._model_timestep(t), device=device, dtype=torch.float32)
                 merged = merged_single = None
                 for line, hint in enumerate(hints):
                     if i >= cn_steps:

@@ -53,6 +53,12 @@ class FlowMatchEulerDiscreteScheduler:
         cfg = self.config
         if cfg.use_dynamic_shifting and mu is None:
             raise ValueError("`mu` must be passed when `use_dynamic_shifting` is set to be `True`")
+        if not cfg.use_dynamic_shifting and sigmas is None and timesteps is None:
+            # diffusers derives the default grid of this branch from sigma_min/sigma_max that its constructor has ALREADY passed
+            # through the static shift; that detail cannot be checked offline and FLUX.1 never takes the branch (its scheduler
+            # config sets use_dynamic_shifting=True) — refuse rather than return a schedule that may differ.
+            raise ValueError("FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=False): pass explicit `sigmas` or `timesteps`; "
+                             "the default sigma grid of the static-shift branch is not reproduced by this build")
         if sigmas is None:
             if timesteps is not None:
                 s = np.asarray(timesteps, dtype=np.float32) / cfg.num_train_timesteps

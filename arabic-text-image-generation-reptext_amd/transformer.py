@@ -138,14 +138,15 @@ class _MMDiTBase(nn.Module, WeightsIO):
         return hit[0], hit[1]
 
     def _temb(self, ws, timestep, guidance, pooled):
-        t1000 = timestep.to(torch.float32).reshape(-1) * 1000.0
+        ref16 = mmdit.REF_BF16_SCALARS
+        t1000 = mmdit.bf16_round_trip_x1000(timestep.reshape(-1)) if ref16 else timestep.to(torch.float32).reshape(-1) * 1000.0
         if t1000.numel() == 1 and ws.B > 1:
             t1000 = t1000.expand(ws.B)
         g1000 = None
         if self.config.guidance_embeds:
             if guidance is None:
                 raise ValueError("guidance_embeds=True requires `guidance`")
-            g1000 = (guidance.to(torch.float32).reshape(-1) * 1000.0).contiguous()
+            g1000 = (mmdit.bf16_round_trip_x1000(guidance.reshape(-1)) if ref16 else guidance.to(torch.float32).reshape(-1) * 1000.0).contiguous()
             if g1000.numel() == 1 and ws.B > 1:
                 g1000 = g1000.expand(ws.B).contiguous()
         return mmdit.time_text_embed(self.time_text_embed, ws, t1000.contiguous(), g1000, pooled)

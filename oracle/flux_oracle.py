@@ -25,6 +25,30 @@ Params = Dict[str, torch.Tensor]
 _STORE: Optional[torch.dtype] = None
 
 
+_REF16_SCALARS = False
+
+
+@contextlib.contextmanager
+def reference_bf16_scalars(on: bool = True):
+    """The scalar roundings of the reference's bf16 run (PIPE:1025 t.to(dtype); PIPE:1048/1094 t/1000 in bf16; CN:282-284
+    timestep.to(dtype)*1000 and guidance.to(dtype)*1000 in bf16): t = 967.3 -> 968, guidance 3.5 -> 3504. Off = exact fp32."""
+    global _REF16_SCALARS
+    prev, _REF16_SCALARS = _REF16_SCALARS, bool(on)
+    try:
+        yield
+    finally:
+        _REF16_SCALARS = prev
+
+
+def _x1000(v: torch.Tensor) -> torch.Tensor:
+    return (v.to(torch.bfloat16) * 1000).float() if _REF16_SCALARS else v.float() * 1000
+
+
+def _model_t(t: torch.Tensor) -> torch.Tensor:
+    """PIPE:1025,1048: what the models get as `timestep` from scheduler value t (= sigma * 1000)."""
+    return (t.to(torch.bfloat16) / 1000).float() if _REF16_SCALARS else t / 1000.0
+
+
 def _s(x: torch.Tensor) -> torch.Tensor:
     return x if _STORE is None else x.to(_STORE).to(torch.float32)
 
@@ -239,8 +263,8 @@ def controlnet_forward(p: Params, cfg: dict, hidden_states, controlnet_cond, enc
     H, Dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
     st = _s if _store_samples else (lambda t: t)
     h = linear(p, "x_embedder", _s(hidden_states)) + linear(p, "controlnet_x_embedder", _s(controlnet_cond))  # CN:277-280
-    t1000 = timestep.float() * 1000                                                                         # CN:282
-    g1000 = guidance.float() * 1000 if (guidance is not None and cfg.get("guidance_embeds", False)) else None
+    t1000 = _x1000(timestep)                                                                                # CN:282
+    g1000 = _x1000(guidance) if (guidance is not None and cfg.get("guidance_embeds", False)) else None
     temb = time_text_embed(p, "time_text_embed", t1000, g1000, pooled_projections)                         # CN:287-291
     e = linear(p, "context_embedder", _s(encoder_hidden_states))                                            # CN:292
     rope = rope_table(torch.cat([txt_ids, img_ids], dim=0).float(), cfg.get("axes_dims_rope", (16, 56, 56)))  # CN:316-317
@@ -265,8 +289,8 @@ def transformer_forward(p: Params, cfg: dict, hidden_states, encoder_hidden_stat
     """FluxTransformer2DModel.forward (A.3), call site PIPE:1092-1104."""
     H, Dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
     h = linear(p, "x_embedder", _s(hidden_states))
-    t1000 = timestep.float() * 1000
-    g1000 = guidance.float() * 1000 if (guidance is not None and cfg.get("guidance_embeds", False)) else None
+    t1000 = _x1000(timestep)
+    g1000 = _x1000(guidance) if (guidance is not None and cfg.get("guidance_embeds", False)) else None
     temb = time_text_embed(p, "time_text_embed", t1000, g1000, pooled_projections)
     e = linear(p, "context_embedder", _s(encoder_hidden_states))
     rope = rope_table(torch.cat([txt_ids, img_ids], dim=0).float(), cfg.get("axes_dims_rope", (16, 56, 56)))
@@ -350,7 +374,7 @@ def denoise_loop(tp: Params, tcfg: dict, cp: Optional[Params], ccfg: Optional[di
     n = len(sigmas) - 1
     for i in range(n):
         t = sigmas[i] * 1000.0                                               # scheduler.timesteps[i]
-        timestep = (t / 1000.0).expand(B)                                    # PIPE:1025,1048
+        timestep = _model_t(t).expand(B)                                     # PIPE:1025,1048
         guidance = torch.full((B,), float(guidance_scale)) if tcfg.get("guidance_embeds", False) else None   # PIPE:1028-1032
         merged = None
         for line, cond in enumerate(control_images):                         # PIPE:1037-1087
@@ -398,7 +422,7 @@ def denoise_loop_inpaint(tp: Params, tcfg: dict, cp: Params, ccfg: dict, ip: Par
     n = len(sigmas) - 1
     for i in range(n):
         B = latents.shape[0]
-        timestep = sigmas[i].expand(B)
+        timestep = _model_t(sigmas[i] * 1000.0).expand(B)
         guidance = torch.full((B,), float(guidance_scale)) if tcfg.get("guidance_embeds", False) else None
         lat_in = latents.expand(pe.shape[0], -1, -1) if cfg_on else latents        # what broadcasting inside the models amounts to
         ts_in = timestep.expand(pe.shape[0]) if cfg_on else timestep

@@ -316,3 +316,47 @@ def test_saved_pipeline_loads_through_hub_id_and_steps_identically(gpu, tmp_path
     assert torch.equal(pipe(**kw).images, pipe2(**kw).images)
     img_a, img_b = pipe(**dict(kw, output_type="np")).images, pipe2(**dict(kw, output_type="np")).images
     assert np.array_equal(img_a, img_b)
+
+
+def test_reference_bf16_scalar_mode_matches_oracle(gpu):
+    """`pipe.reference_bf16_scalars = True` rounds t, t/1000 and guidance*1000 to bf16 where the reference's bf16
+    run does (PIPE:1025,1048; CN:282-284: t = 622.46 -> 624, guidance 3.5 -> 3504). The oracle has the same switch; the default of
+    both is the exact fp32 scalar. Each mode agrees with its oracle; the two modes differ by more than the tolerance."""
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.pipeline import FluxControlNetPipeline
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    cfg_t = dict(WIDE_T, num_attention_heads=4, joint_attention_dim=256, pooled_projection_dim=64, num_layers=2, num_single_layers=2)
+    cfg_c = dict(cfg_t, num_layers=2, num_single_layers=0, extra_condition_channels=64)
+    tp, cp = orc.init_mmdit_params(cfg_t, seed=51), orc.init_mmdit_params(cfg_c, seed=52, controlnet=True)
+    tr = FluxTransformer2DModel(**cfg_t, device=gpu, dtype=torch.bfloat16)
+    cn = FluxControlNetModel(**cfg_c, device=gpu, dtype=torch.bfloat16)
+    tr.load_state_dict(tp)
+    cn.load_state_dict(cp)
+    pipe = FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), None, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
+    N, T = 256, 64
+    pe, pooled, hint, lat0 = r(1, T, 256), r(1, 64), r(1, N, 128), r(1, N, 64)
+    sig = orc.flow_sigmas(3, orc.calculate_shift(N, 256, 4096, 0.5, 1.15))
+    ids, tids = orc.latent_image_ids(32, 32), torch.zeros(T, 3)
+    kw = dict(prompt_embeds=pe.to(gpu, torch.bfloat16), pooled_prompt_embeds=pooled.to(gpu, torch.bfloat16), height=256, width=256,
+              num_inference_steps=3, guidance_scale=3.5, control_image=[hint.to(gpu, torch.bfloat16)], latents=lat0.to(gpu, torch.bfloat16),
+              output_type="latent")
+    try:
+        out_exact = pipe(**kw).images.float().cpu()
+        pipe.reference_bf16_scalars = True
+        out_ref16 = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.reference_bf16_scalars = False
+        pipe._model_timestep(1.0)                    # resets the module-level switch
+    ref_exact = orc.denoise_loop(tp, cfg_t, cp, cfg_c, lat0, pe, pooled, [hint], [None], sig, ids, tids, 3.5)
+    with orc.reference_bf16_scalars():
+        ref_ref16 = orc.denoise_loop(tp, cfg_t, cp, cfg_c, lat0, pe, pooled, [hint], [None], sig, ids, tids, 3.5)
+    e_exact, e_ref16, gap = rel_l2(out_exact, ref_exact), rel_l2(out_ref16, ref_ref16), rel_l2(ref_ref16, ref_exact)
+    print(f"scalar modes: exact {e_exact:.3e}, reference-bf16 {e_ref16:.3e}; the two oracles differ by {gap:.3e}")
+    assert e_exact < 1.5e-3 and e_ref16 < 1.5e-3
+    assert gap > 2 * max(e_exact, e_ref16)           # the rounding of the scalars is visible well above the parity error
+    assert rel_l2(out_ref16, ref_exact) > 2 * e_ref16

@@ -84,3 +84,29 @@ def test_resize_img_matches_script_arithmetic():
     assert out.size == (1280, 832)
     assert hints.resize_img(im, size=(640, 320)).size == (640, 320)
     assert hints.resize_img(im, pad_to_max_side=True).size == (1280, 1280)
+
+
+def test_canny_multichannel_takes_the_strongest_channel_not_luma():
+    """ADVICE round 1: infer.py:16-22 gives cv2.Canny the 3-channel glyph; cv::Canny with cn > 1 keeps, per pixel, the channel
+    with the largest |dx|+|dy|. Pure blue text (0,0,128) has luma 15 — a gray conversion would lose the whole contour."""
+    font = ImageFont.truetype("DejaVuSans.ttf", 48)
+    from PIL import ImageDraw
+
+    def glyph(color):
+        im = Image.new("RGB", (256, 128), (0, 0, 0))
+        ImageDraw.Draw(im).text((20, 30), "Text", font=font, fill=color)
+        return np.array(im)
+
+    e_white, e_blue, e_red = (hints.canny_edges(glyph(c)) for c in ((255, 255, 255), (0, 0, 128), (200, 0, 0)))
+    assert e_blue.any() and e_red.any()
+    # same glyph geometry -> (nearly) the same contour whatever the colour: the anti-aliased ramps scale with the colour value
+    agree = lambda a, b: float(((a > 0) & (b > 0)).sum()) / float((a > 0).sum())
+    assert agree(e_white, e_red) > 0.85 and agree(e_white, e_blue) > 0.8
+    # a rectangle in one channel only: identical to the single-channel result of that channel
+    img = np.zeros([80, 120, 3], dtype=np.uint8)
+    img[20:60, 30:90, 2] = 128
+    assert np.array_equal(hints.canny_edges(img), hints.canny_edges(img[..., 2]))
+    # gray images (all channels equal) are unchanged by the multi-channel rule
+    g = np.zeros([80, 120], dtype=np.uint8)
+    g[20:60, 30:90] = 255
+    assert np.array_equal(hints.canny_edges(np.stack([g] * 3, axis=2)), hints.canny_edges(g))

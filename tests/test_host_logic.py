@@ -320,3 +320,30 @@ def test_pipeline_from_pretrained_reads_model_index(tmp_path, monkeypatch):
     os.rename(os.path.join(snap, "vae"), os.path.join(snap, "vae_gone"))
     with pytest.raises(OSError, match="vae"):
         FluxControlNetPipeline.from_pretrained("black-forest-labs/FLUX.1-dev", controlnet=pipe.controlnet)
+
+
+def test_reference_bf16_scalar_mode_and_static_shift_guard():
+    """ADVICE round 1 (low): the reference's bf16 run rounds t, t/1000 and guidance·1000 to bf16 (PIPE:1025,1048; CN:282-284);
+    the default path keeps them exact. Both modes exist in the pipeline and in the oracle and agree on the values."""
+    from reptext_amd import mmdit
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+
+    pipe = _cpu_pipe()
+    assert pipe._model_timestep(967.3) == 967.3 / 1000.0
+    pipe.reference_bf16_scalars = True
+    mt = pipe._model_timestep(967.3)
+    assert mt == float((torch.tensor(967.3).to(torch.bfloat16) / 1000).float()) and mt != 967.3 / 1000.0
+    assert float(mmdit.bf16_round_trip_x1000(torch.tensor([mt]))[0]) == 968.0                       # 967.3 enters the sinusoid as 968
+    assert float(mmdit.bf16_round_trip_x1000(torch.tensor([3.5]))[0]) == 3504.0                     # guidance 3.5 -> 3504
+    with orc.reference_bf16_scalars():
+        assert float(orc._x1000(orc._model_t(torch.tensor(967.3)))) == 968.0 and float(orc._x1000(torch.tensor(3.5))) == 3504.0
+    assert float(orc._x1000(orc._model_t(torch.tensor(967.3)))) == pytest.approx(967.3, rel=1e-6)
+    pipe.reference_bf16_scalars = False
+    pipe._model_timestep(1.0)
+    assert mmdit.REF_BF16_SCALARS is False
+    # static-shift branch: explicit sigmas work, the unverifiable default grid is refused
+    s = FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=False, shift=3.0)
+    s.set_timesteps(sigmas=[1.0, 0.5])
+    assert s.sigmas.tolist() == pytest.approx([1.0, 0.75, 0.0])
+    with pytest.raises(ValueError, match="static-shift"):
+        s.set_timesteps(4)
