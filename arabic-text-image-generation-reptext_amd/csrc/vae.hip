@@ -378,6 +378,70 @@ inline int grid_for(int64_t n, int block) {
 
 }  // namespace
 
+// ---- torch.nn.functional.interpolate on [planes][H][W] fp32 (or uint8 * in_scale) -> fp32, modes "nearest" and "bilinear"
+// with align_corners=False, antialias=False: the pipelines' regional-mask /16 (PIPE:1010-1012), glyph-mask (PIPE:645-650) and
+// inpaint-mask (INP:813) resizes. Same source-index rule and the same fp32 expression order as ATen's upsample kernels:
+//   ratio = scales given ? 1/scale : in/out;  nearest: src = min(floor(dst * ratio), in-1)
+//   bilinear: real = max(ratio*(dst+0.5)-0.5, 0); i0 = (int)real; i1 = i0 + (i0 < in-1); l1 = real - i0; l0 = 1 - l1
+//             out = fma(h1*w1, p11, fma(h1*w0, p10, fma(h0*w1, p01, (h0*w0)*p00)))
+// The four tap weights are formed first and the taps accumulated in that order — the order ATen's CPU kernel (torch 2.10)
+// was found to use: bit-identical for the power-of-two ratios the pipelines have (16, 8; every product is then exact),
+// within one fp32 ulp otherwise (ATen's own result there depends on its vector ISA path). Roundings are explicit (__f*_rn).
+__global__ void resize2d_kernel(const void* __restrict__ in, int in_u8, float in_scale, float* __restrict__ out, int planes, int H, int W,
+                                int OH, int OW, float rh, float rw, int bilinear) {
+#pragma clang fp contract(off)          // every rounding step below is the one ATen takes; no silent mul+add fusion
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)planes * OH * OW) return;
+  const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), p = (int)(idx / ((int64_t)OW * OH));
+  auto px = [&](int y, int x) -> float {
+    const int64_t o = ((int64_t)p * H + y) * W + x;
+    return in_u8 ? (float)reinterpret_cast<const uint8_t*>(in)[o] / in_scale : reinterpret_cast<const float*>(in)[o];
+  };
+  if (!bilinear) {
+    const int sy = min((int)floorf((float)oy * rh), H - 1), sx = min((int)floorf((float)ox * rw), W - 1);
+    out[idx] = px(sy, sx);
+    return;
+  }
+  const float ry = fmaxf(__fsub_rn(__fmul_rn(rh, (float)oy + 0.5f), 0.5f), 0.f), rx = fmaxf(__fsub_rn(__fmul_rn(rw, (float)ox + 0.5f), 0.5f), 0.f);
+  const int y0 = (int)ry, x0 = (int)rx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float h1 = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), w1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
+  const float h0 = 1.f - h1, w0 = 1.f - w1;
+  float acc = __fmul_rn(__fmul_rn(h0, w0), px(y0, x0));
+  acc = __fmaf_rn(__fmul_rn(h0, w1), px(y0, x1), acc);
+  acc = __fmaf_rn(__fmul_rn(h1, w0), px(y1, x0), acc);
+  out[idx] = __fmaf_rn(__fmul_rn(h1, w1), px(y1, x1), acc);
+}
+
+// 0.10 * glyph latent + noise where the bilinearly down-sampled glyph mask is > 0, else noise (PIPE:645-654 / INP:640-647):
+// mask = any channel of the [-1,1]-normalised glyph image > 0, resized to the latent grid as above, thresholded at > 0.
+__global__ void glyph_blend_kernel(const float* __restrict__ img, const float* __restrict__ lat, const float* __restrict__ noise,
+                                   float* __restrict__ out, int B, int Cimg, int H, int W, int Cl, int OH, int OW, float rh, float rw) {
+#pragma clang fp contract(off)          // torch computes 0.10 * lat and the sum as two roundings
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * OH * OW) return;
+  const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), b = (int)(idx / ((int64_t)OW * OH));
+  auto m = [&](int y, int x) -> float {
+    bool any = false;
+    for (int c = 0; c < Cimg; ++c) any = any || img[(((int64_t)b * Cimg + c) * H + y) * W + x] > 0.f;
+    return any ? 1.f : 0.f;
+  };
+  const float ry = fmaxf(__fsub_rn(__fmul_rn(rh, (float)oy + 0.5f), 0.5f), 0.f), rx = fmaxf(__fsub_rn(__fmul_rn(rw, (float)ox + 0.5f), 0.5f), 0.f);
+  const int y0 = (int)ry, x0 = (int)rx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float h1 = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), w1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
+  const float h0 = 1.f - h1, w0 = 1.f - w1;
+  float acc = __fmul_rn(__fmul_rn(h0, w0), m(y0, x0));                       // the mask is 0/1 and the weights are >= 0: any order gives
+  acc = __fmaf_rn(__fmul_rn(h0, w1), m(y0, x1), acc);                        // the same sign, which is all that is used
+  acc = __fmaf_rn(__fmul_rn(h1, w0), m(y1, x0), acc);
+  const bool on = __fmaf_rn(__fmul_rn(h1, w1), m(y1, x1), acc) > 0.f;
+  for (int c = 0; c < Cl; ++c) {
+    const int64_t o = (((int64_t)b * Cl + c) * OH + oy) * OW + ox;
+    const float scaled = 0.10f * lat[o];        // plain operators: the pragma above applies to them (not to header intrinsics)
+    out[o] = on ? scaled + noise[o] : noise[o];
+  }
+}
+
 extern "C" {
 
 int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y, int32_t B, int32_t Hs,
@@ -484,6 +548,24 @@ int rt_unpack_latents_haloed(const void* packed, void* y, int32_t B, int32_t C, 
   if (!packed || !y || B < 1 || C < 1 || H2 < 2 || W2 < 2 || H2 % 2 || W2 % 2 || Cp < C) return RT_E_BADARG;
   hipLaunchKernelGGL(unpack_to_haloed_kernel, dim3(grid_for((int64_t)B * H2 * W2 * Cp, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)packed, (bf16_t*)y, B, C, H2, W2, Cp, inv_scale, shift);
+  return rt_hip_status();
+}
+
+int rt_resize2d(const void* in, int32_t in_u8, float in_scale, float* out, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                float scale_h, float scale_w, int32_t bilinear, void* stream) {
+  if (!in || !out || planes < 1 || H < 1 || W < 1 || OH < 1 || OW < 1 || (in_u8 && in_scale == 0.f)) return RT_E_BADARG;
+  // ATen: ratio = (float)(1.0 / (double)scale) when a scale factor was given, else (float)in / out
+  const float rh = scale_h > 0.f ? (float)(1.0 / (double)scale_h) : (float)H / (float)OH, rw = scale_w > 0.f ? (float)(1.0 / (double)scale_w) : (float)W / (float)OW;
+  hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for((int64_t)planes * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, in, in_u8, in_scale,
+                     out, planes, H, W, OH, OW, rh, rw, bilinear);
+  return rt_hip_status();
+}
+
+int rt_glyph_blend(const float* image, const float* latents, const float* noise, float* out, int32_t B, int32_t Cimg, int32_t H, int32_t W,
+                   int32_t Cl, int32_t OH, int32_t OW, void* stream) {
+  if (!image || !latents || !noise || !out || B < 1 || Cimg < 1 || H < 1 || W < 1 || Cl < 1 || OH < 1 || OW < 1) return RT_E_BADARG;
+  hipLaunchKernelGGL(glyph_blend_kernel, dim3(grid_for((int64_t)B * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, image, latents, noise,
+                     out, B, Cimg, H, W, Cl, OH, OW, (float)H / (float)OH, (float)W / (float)OW);
   return rt_hip_status();
 }
 

@@ -91,6 +91,8 @@ SIGNATURES.update({
     "rt_nchw_to_haloed_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_haloed_nhwc_to_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_unpack_latents_haloed": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+    "rt_resize2d": [_vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
+    "rt_glyph_blend": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
 })
 
 # entries that do not return a status code

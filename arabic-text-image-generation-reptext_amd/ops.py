@@ -428,3 +428,41 @@ def silu_split(x: torch.Tensor, apply_silu: bool = True):
     lo = torch.empty(x.shape, device=x.device, dtype=BF16)
     native.check("rt_silu_split_bf16", native.load().rt_silu_split_bf16(_dev(x, "x", F32), hi.data_ptr(), lo.data_ptr(), x.numel(), int(apply_silu), _stream()))
     return hi, lo
+
+
+def resize2d(x: torch.Tensor, size=None, scale_factor: Optional[float] = None, mode: str = "nearest", u8_scale: Optional[float] = None) -> torch.Tensor:
+    """torch.nn.functional.interpolate(x, size=/scale_factor=, mode="nearest"|"bilinear", align_corners=False) on the device,
+    bit-identical to ATen: x [..., H, W] fp32 — or uint8 with ``u8_scale`` (x / u8_scale is resized) — -> fp32 [..., OH, OW]."""
+    if mode not in ("nearest", "bilinear"):
+        raise ValueError("resize2d: mode must be 'nearest' or 'bilinear'")
+    if (size is None) == (scale_factor is None):
+        raise ValueError("resize2d: exactly one of size / scale_factor")
+    x = x.contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    if size is not None:
+        OH, OW = int(size[0]), int(size[1])
+        sf = 0.0
+    else:
+        OH, OW = int(H * float(scale_factor)), int(W * float(scale_factor))   # floor(in * scale), as torch computes the size
+        sf = float(scale_factor)
+    is_u8 = x.dtype == torch.uint8
+    if is_u8 != (u8_scale is not None) or (not is_u8 and x.dtype != F32):
+        raise TypeError("resize2d: fp32 input, or uint8 input together with u8_scale")
+    planes = x.numel() // (H * W)
+    out = torch.empty(*x.shape[:-2], OH, OW, device=x.device, dtype=F32)
+    native.check("rt_resize2d", native.load().rt_resize2d(_dev(x, "x"), int(is_u8), float(u8_scale or 1.0), out.data_ptr(), planes, H, W, OH, OW,
+                                                      sf, sf, int(mode == "bilinear"), _stream()))
+    return out
+
+
+def glyph_blend(image: torch.Tensor, latents: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """where(bilinear-resized (image > 0).any(channel) > 0, 0.10 * latents + noise, noise) — PIPE:645-654; all fp32, on the device."""
+    image, latents, noise = image.contiguous(), latents.contiguous(), noise.contiguous()
+    if image.dim() != 4 or latents.shape != noise.shape or latents.dim() != 4 or image.shape[0] != latents.shape[0]:
+        raise ValueError("glyph_blend: image [B,C,H,W], latents/noise [B,Cl,OH,OW]")
+    B, Cimg, H, W = image.shape
+    _, Cl, OH, OW = latents.shape
+    out = torch.empty_like(noise)
+    native.check("rt_glyph_blend", native.load().rt_glyph_blend(_dev(image, "image", F32), _dev(latents, "latents", F32), _dev(noise, "noise", F32),
+                                                             out.data_ptr(), B, Cimg, H, W, Cl, OH, OW, _stream()))
+    return out

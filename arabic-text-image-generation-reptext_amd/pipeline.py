@@ -366,7 +366,10 @@ class FluxControlNetPipeline:
         return self._pack_latents(noise, batch_size, num_channels_latents, h2, w2), ids
 
     def _glyph_blend(self, image, image_latents, noise):
-        """0.10·glyph latent + noise where the bilinearly down-sampled glyph mask is > 0 (PIPE:645-654)."""
+        """0.10·glyph latent + noise where the bilinearly down-sampled glyph mask is > 0 (PIPE:645-654). On the GPU one HIP
+        kernel (mask, resize, threshold, blend: ops.glyph_blend, bit-identical resize to F.interpolate); torch ops on the CPU."""
+        if image.is_cuda:
+            return ops.glyph_blend(image.to(torch.float32), image_latents.to(torch.float32), noise.to(torch.float32)).to(noise.dtype)
         m = (image > 0).any(dim=1, keepdim=True).float()
         m = F.interpolate(m, size=noise.shape[-2:], mode="bilinear", align_corners=False) > 0
         return torch.where(m, 0.10 * image_latents + noise, noise)
@@ -412,11 +415,17 @@ class FluxControlNetPipeline:
         return packed, height, width
 
     def _region_masks(self, control_mask, device, dtype) -> List[torch.Tensor]:
-        """PIPE:1007-1013: mask/255 -> bilinear x1/16 -> [1, N, 1]."""
+        """PIPE:1007-1013: mask/255 -> bilinear x1/16 -> [1, N, 1]. uint8 masks headed for the GPU are divided and resized
+        there (ops.resize2d: same source-index rule and fp32 expression order as F.interpolate, bit-identical)."""
         out = []
         if control_mask is not None:
             for m in control_mask:
-                rm = torch.from_numpy(np.array(m)) / 255.0
+                arr = np.array(m)
+                if torch.device(device).type == "cuda" and arr.dtype == np.uint8 and arr.ndim == 2:
+                    t = ops.resize2d(torch.from_numpy(arr).to(device)[None, None], scale_factor=1 / 16, mode="bilinear", u8_scale=255.0)
+                    out.append(t.reshape([1, -1, 1]).to(dtype))
+                    continue
+                rm = torch.from_numpy(arr) / 255.0
                 t = F.interpolate(rm[None, None].float(), scale_factor=1 / 16, mode="bilinear").reshape([1, -1, 1])
                 out.append(t.to(device=device, dtype=dtype))
         return out

@@ -97,7 +97,8 @@ class FluxControlNetPipeline(_BasePipeline):
         masked = torch.where((mask > 0.5).repeat(1, 3, 1, 1), torch.full_like(image, -1.0), image)
         lat = self.vae.encode(masked.to(self.vae.dtype)).latent_dist.sample()
         lat = ((lat - self.vae.config.shift_factor) * self.vae.config.scaling_factor).to(dtype)
-        m = F.interpolate(mask.float(), size=(height // self.vae_scale_factor * 2, width // self.vae_scale_factor * 2)).to(dtype)
+        msize = (height // self.vae_scale_factor * 2, width // self.vae_scale_factor * 2)
+        m = (ops.resize2d(mask.float(), size=msize, mode="nearest") if mask.is_cuda else F.interpolate(mask.float(), size=msize)).to(dtype)
         both = torch.cat([lat, 1 - m], dim=1)
         packed = self._pack_latents(both, batch_size * num_images_per_prompt, both.shape[1], both.shape[2], both.shape[3])
         if do_classifier_free_guidance:

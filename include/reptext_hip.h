@@ -250,6 +250,20 @@ int rt_haloed_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_
 int rt_unpack_latents_haloed(const void* packed, void* y, int32_t B, int32_t C, int32_t H2, int32_t W2, int32_t Cp,
                              float inv_scale, float shift, void* stream);
 
+
+/* Hint-side resizes of the pipelines on the device, with torch.nn.functional.interpolate's rules
+ * (align_corners=False, no antialias; the same fp32 expression order as ATen, so results are bit-identical):
+ *   PIPE:1010-1012  regional mask / 255 -> bilinear x 1/16          (in_u8 = 1, in_scale = 255, scale = 1/16)
+ *   INP:813         inpaint mask -> nearest, to the latent grid      (bilinear = 0, scale = 0: ratio = in/out)
+ * `in`: uint8 (in_u8, divided by in_scale first) or f32 [planes][H][W]; out f32 [planes][OH][OW]; scale_h/scale_w > 0 are the
+ * `scale_factor` torch was given (ratio = 1/scale), 0 = derive the ratio from the sizes. */
+int rt_resize2d(const void* in, int32_t in_u8, float in_scale, float* out, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                float scale_h, float scale_w, int32_t bilinear, void* stream);
+/* PIPE:645-654 / INP:640-647: out = 0.10 * latents + noise where the glyph mask (any channel of image > 0), bilinearly resized
+ * to the latent grid, is > 0; noise elsewhere. image f32 [B][Cimg][H][W]; latents, noise, out f32 [B][Cl][OH][OW]. */
+int rt_glyph_blend(const float* image, const float* latents, const float* noise, float* out, int32_t B, int32_t Cimg, int32_t H, int32_t W,
+                   int32_t Cl, int32_t OH, int32_t OW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -427,3 +427,85 @@ def test_c_abi_from_plain_cpp_host(gpu, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------- hint-side resizes
+def test_resize2d_is_bit_identical_to_interpolate(ops, gpu):
+    """ops.resize2d against torch.nn.functional.interpolate on the CPU: the /16 bilinear regional mask of PIPE:1010-1012
+    (uint8 / 255 first), size-driven bilinear (the glyph mask, PIPE:649) and nearest (INP:813). Bit for bit wherever the
+    resize ratio is a power of two (16 and 8 are what the pipelines use; all tap weights are then exact) and for nearest;
+    within one fp32 ulp for other ratios, where ATen's own CPU result depends on its vector code path."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    for H, W in [(1024, 1024), (256, 384), (250, 330), (33, 17)]:
+        m = (torch.rand(H, W, generator=g) > 0.6).to(torch.uint8) * 255
+        m[H // 3 : H // 2, W // 4 : W // 2] = 255
+        m[0, 0] = 77                                                      # a non-binary value: the division must match too
+        ref = F.interpolate((m / 255.0)[None, None].float(), scale_factor=1 / 16, mode="bilinear")
+        got = ops.resize2d(m.to(gpu)[None, None], scale_factor=1 / 16, mode="bilinear", u8_scale=255.0)
+        assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (H, W)
+    x = torch.randn(2, 3, 96, 160, generator=g)
+    for size in [(12, 20), (48, 80), (6, 10), (37, 51), (200, 300)]:
+        for mode in ("bilinear", "nearest"):
+            kw = dict(align_corners=False) if mode == "bilinear" else {}
+            ref = F.interpolate(x, size=size, mode=mode, **kw)
+            got = ops.resize2d(x.to(gpu), size=size, mode=mode).cpu()
+            if mode == "nearest" or size in [(12, 20), (48, 80), (6, 10)]:
+                assert torch.equal(got, ref), (size, mode)
+            else:
+                assert float((got - ref).abs().max()) <= 4.8e-7, (size, mode)      # one ulp at |x| < 4
+    ref = F.interpolate(x, scale_factor=0.5, mode="bilinear")
+    assert torch.equal(ops.resize2d(x.to(gpu), scale_factor=0.5, mode="bilinear").cpu(), ref)
+
+
+def test_glyph_blend_matches_torch(ops, gpu):
+    """PIPE:645-654: where(interpolate((img > 0).any(1)) > 0, 0.10 * lat + noise, noise) as one kernel."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(1)
+    img = -torch.ones(2, 3, 256, 320)
+    img[0, :, 60:120, 100:200] = torch.rand(3, 60, 100, generator=g) * 2 - 1
+    img[1, 1, 7, 9] = 0.5                                                 # a single lit pixel in one channel
+    lat, noise = torch.randn(2, 16, 32, 40, generator=g), torch.randn(2, 16, 32, 40, generator=g)
+    m = F.interpolate((img > 0).any(dim=1, keepdim=True).float(), size=(32, 40), mode="bilinear", align_corners=False) > 0
+    ref = torch.where(m, 0.10 * lat + noise, noise)
+    got = ops.glyph_blend(img.to(gpu), lat.to(gpu), noise.to(gpu)).cpu()
+    assert torch.equal(got, ref) and bool(m.any()) and not bool(m.all())
+
+
+def test_torch_library_custom_ops_match_direct_calls(ops, gpu):
+    """SURVEY §8b / north_star wording: the kernels are also registered as PyTorch custom ops (torch.ops.reptext_amd.*,
+    reptext_amd/torch_ops.py). Same kernels behind the dispatcher: results are bit-identical to the direct ctypes calls, a CPU
+    tensor is refused, and a whole model forward routed through the dispatcher equals the direct one."""
+    import reptext_amd.torch_ops as tops
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    g = torch.Generator(device=gpu).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=gpu, generator=g).to(torch.bfloat16)
+    a, w, b = r(300, 256), r(520, 256) * 0.05, r(520)
+    res = torch.randn(300, 520, device=gpu, generator=g)
+    o1, o2 = torch.empty(300, 520, device=gpu), torch.empty(300, 520, device=gpu)
+    ops.linear(a, w, o1, bias=b, res=res, gelu_from=256)
+    torch.ops.reptext_amd.linear(a, w, o2, b, None, res, None, None, 256, 1.0)
+    assert torch.equal(o1, o2)
+    qkv = r(2, 200, 3 * 256)
+    a1, a2 = torch.empty(2, 200, 256, device=gpu, dtype=torch.bfloat16), torch.empty(2, 200, 256, device=gpu, dtype=torch.bfloat16)
+    ops.attention(qkv[..., :256], qkv[..., 256:512], qkv[..., 512:], a1, 2)
+    torch.ops.reptext_amd.attention(qkv[..., :256], qkv[..., 256:512], qkv[..., 512:], a2, 2)
+    assert torch.equal(a1, a2)
+    with pytest.raises(NotImplementedError):
+        torch.ops.reptext_amd.attention(qkv.cpu()[..., :256], qkv.cpu()[..., 256:512], qkv.cpu()[..., 512:], a2.cpu(), 2)
+    cfg = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2,
+               joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    tr = FluxTransformer2DModel(**cfg, device=gpu, dtype=torch.bfloat16).random_init_(1)
+    kw = dict(hidden_states=r(1, 64, 64), encoder_hidden_states=r(1, 32, 128), pooled_projections=r(1, 64), timestep=torch.full((1,), 0.5, device=gpu),
+              guidance=torch.full((1,), 3.5, device=gpu), img_ids=orc.latent_image_ids(16, 16).to(gpu, torch.bfloat16),
+              txt_ids=torch.zeros(32, 3, device=gpu, dtype=torch.bfloat16), return_dict=False)
+    v_direct = tr(**kw)[0].clone()
+    tops.enable_dispatch(True)
+    try:
+        v_dispatch = tr(**kw)[0].clone()
+    finally:
+        tops.enable_dispatch(False)
+    assert torch.equal(v_direct, v_dispatch)
