@@ -35,8 +35,10 @@ def _worker(rank, world, port, q, shared):
     lo, hi = rd.shard_range(G, rank, world)
     mine = got.shard(lo, hi)
     noise = rd.sample_noise(range(lo, hi), (4, 4), 42, torch.float32, "cpu")
-    q.put((rank, (lo, hi), mine.prompt_embeds.contiguous(), mine.pooled.contiguous(), [h.contiguous() for h in mine.hints],
-           [m.contiguous() for m in mine.masks], noise, got.masks[1].dtype, got.prompt_embeds.dtype))
+    # numpy copies: pickled by value (torch tensors would travel as shared-memory handles that die with this process)
+    npy = lambda t: t.contiguous().float().numpy().copy()
+    q.put((rank, (lo, hi), npy(mine.prompt_embeds), npy(mine.pooled), [npy(h) for h in mine.hints], [npy(m) for m in mine.masks], npy(noise),
+           str(got.masks[1].dtype), str(got.prompt_embeds.dtype)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,15 +67,15 @@ def test_broadcast_and_sharding_world2():
     for shared in (False, True):
         r0, r1 = _run_world2(shared)
         assert r0[1] == (0, 3) and r1[1] == (3, 5)
-        assert r0[7] == torch.float32 and r0[8] == torch.bfloat16                     # masks stay fp32, embeddings bf16
+        assert r0[7] == "torch.float32" and r0[8] == "torch.bfloat16"                 # masks stay fp32, embeddings bf16
         # what a single process (world 1) feeds for the same global batch
         full = _conditioning(shared).shard(0, G)
-        cat = lambda i: torch.cat([r0[i], r1[i]])
+        cat = lambda i: torch.cat([torch.from_numpy(r0[i]), torch.from_numpy(r1[i])])
         assert torch.equal(cat(2).float(), full.prompt_embeds.contiguous()) and torch.equal(cat(3).float(), full.pooled.contiguous())
         for line in range(2):
-            assert torch.equal(torch.cat([r0[4][line], r1[4][line]]).float(), full.hints[line].contiguous())
-            assert torch.equal(torch.cat([r0[5][line], r1[5][line]]), full.masks[line].contiguous())
-        assert torch.equal(torch.cat([r0[6], r1[6]]), rd.sample_noise(range(G), (4, 4), 42, torch.float32, "cpu"))   # noise by global sample id
+            assert torch.equal(torch.cat([torch.from_numpy(r0[4][line]), torch.from_numpy(r1[4][line])]), full.hints[line].contiguous())
+            assert torch.equal(torch.cat([torch.from_numpy(r0[5][line]), torch.from_numpy(r1[5][line])]), full.masks[line].contiguous())
+        assert torch.equal(cat(6), rd.sample_noise(range(G), (4, 4), 42, torch.float32, "cpu"))   # noise by global sample id
 
 
 def test_conditioning_shard_rules():
