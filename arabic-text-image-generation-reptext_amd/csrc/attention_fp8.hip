@@ -149,8 +149,15 @@ __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * BQ;
+  // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so blockIdx.x & 7 labels the XCD group;
+  // each group owns a CONTIGUOUS run of the (head, query block) items — whole heads — so a head's K/Vᵀ stay in one XCD's L2.
+  const int nqb = (S + BQ - 1) / BQ, NI = H * nqb;
+  const int xcd = (int)blockIdx.x & 7, xslot = (int)blockIdx.x >> 3, b = (int)blockIdx.y;
+  const int ibase = NI >> 3, iextra = NI & 7;
+  if (xslot >= ibase + (xcd < iextra ? 1 : 0)) return;                       // padding workgroup of a group with one item fewer
+  const int item = xcd * ibase + (xcd < iextra ? xcd : iextra) + xslot;
+  const int head = item / nqb;
+  const int q0 = (item - head * nqb) * BQ;
   const int ldqk = 2 * H * DH;
 
   const uint8_t* Qb = qk8 + (int64_t)b * S * ldqk + head * DH;
@@ -367,7 +374,8 @@ extern "C" int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, i
   if (ldo < (int64_t)H * DH) return RT_E_SHAPE;
   if ((int64_t)(S + BKV) * 2 * H * DH >= (int64_t)1 << 31) return RT_E_SHAPE;      // per-tile byte offsets are 32-bit
   const int S64 = (S + BKV - 1) / BKV * BKV;
-  const dim3 grid((S + BQ - 1) / BQ, H, B);
+  const int NI = H * ((S + BQ - 1) / BQ);
+  const dim3 grid(8 * ((NI + 7) / 8), B);
   hipLaunchKernelGGL(attention_fp8_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream, (const uint8_t*)qk8, (const uint8_t*)vt8,
                      (bf16_t*)o, ldo, stride_ob, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE));
   return rt_hip_status();

@@ -67,7 +67,9 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     }
   }
   // gate depends on (batch, row / rpb): constant over the tile unless the tile straddles batch entries (rpb < M)
-  const bool gate_per_row = g.gate && (rpb < g.M);
+  // e4m3 instantiation: 16 more registers hold the de-quantisation scales, so the tile-constant gate vectors are re-read per
+  // row there (L1 hits) instead of being kept — that was the 4-VGPR spill of gemm_pp_kernel<true>.
+  const bool gate_per_row = g.gate && ((rpb < g.M) || FP8);
   if (g.gate && !gate_per_row) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
