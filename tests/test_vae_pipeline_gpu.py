@@ -375,6 +375,58 @@ def test_tower_stream_overlap_is_bitwise_neutral(vae_pair, gpu, monkeypatch):
         assert torch.equal(pipe(**kw).images, serial)
 
 
+def test_denoise_loop_graph_replay_is_bitwise_the_eager_loop(vae_pair, gpu):
+    """pipeline.GRAPH_CAPTURE: the first call of a signature runs eagerly, the second captures the whole loop (two text lines, tower
+    off after step 2 of 3) into one hipGraph, later calls replay it with new inputs copied into its static buffers. Every result
+    must equal the eager loop bit for bit — also for inputs the graph has never seen and after the weights were changed in place."""
+    import reptext_amd.pipeline as P
+    from PIL import Image
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16).random_init_(71)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16).random_init_(72)
+    pipe = P.FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g).to(gpu, torch.bfloat16)
+    masks = []
+    for box in ((40, 120, 30, 200), (140, 220, 60, 240)):
+        m = np.zeros([256, 256], dtype=np.uint8); m[box[0]:box[1], box[2]:box[3]] = 255
+        masks.append(Image.fromarray(m))
+
+    def inputs():
+        return dict(prompt_embeds=r(1, 64, 256), pooled_prompt_embeds=r(1, 64), control_image=[r(1, 256, 128), r(1, 256, 128)], latents=r(1, 256, 64))
+
+    fixed = dict(height=256, width=256, num_inference_steps=3, guidance_scale=3.5, control_mask=masks, controlnet_conditioning_step=2, output_type="latent")
+    a, b = inputs(), inputs()
+    pipe.capture_graphs = False
+    ref_a, ref_b = pipe(**a, **fixed).images.clone(), pipe(**b, **fixed).images.clone()
+    assert not torch.equal(ref_a, ref_b)
+    pipe.capture_graphs = True
+    assert torch.equal(pipe(**a, **fixed).images, ref_a)                       # eager, signature remembered
+    assert torch.equal(pipe(**a, **fixed).images, ref_a)                       # captured + replayed
+    ent = [v for v in pipe._graph_cache.values() if isinstance(v, dict)]
+    assert len(ent) == 1                                                        # a graph exists for this signature
+    assert torch.equal(pipe(**b, **fixed).images, ref_b)                       # replay on inputs the capture never saw
+    assert torch.equal(pipe(**a, **fixed).images, ref_a)
+    assert pipe.scheduler._step_index == 3                                      # what the eager loop leaves behind
+    # weights changed in place (same storage): the graph reads the new values
+    tr.random_init_(73)
+    got = pipe(**a, **fixed).images.clone()
+    pipe.capture_graphs = False
+    assert torch.equal(got, pipe(**a, **fixed).images)
+    assert not torch.equal(got, ref_a)
+    # a different signature (2 steps) is not served by the 3-step graph
+    pipe.capture_graphs = True
+    two = dict(fixed, num_inference_steps=2)
+    out2 = pipe(**a, **two).images.clone()
+    pipe.capture_graphs = False
+    assert torch.equal(out2, pipe(**a, **two).images)
+
+
 def test_pipeline_fp8_linears(vae_pair, gpu):
     """Config-5 precision through the whole loop (C1 shape, 4 steps, masked tower): latents vs the fp32 oracle and vs the oracle
     with the same e4m3 quantisation points; the GPU must sit on that run's floor."""
