@@ -60,6 +60,11 @@ struct AttnGeom {
   int split;                   // key-split tail enabled (workspace present and it pays)
 };
 
+// Wave-uniform conditions that are almost never true (ragged last tile, a row maximum that outgrew the running one): tell the
+// block placement so, so that the rare code sits out of line and the common path falls through.
+#define RT_RARE(c) __builtin_expect(!!(c), 0)
+#define RT_USUAL(c) __builtin_expect(!!(c), 1)
+
 __device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // 3-input max. Plain fmaxf so the compiler inserts the MFMA->VALU wait states itself: an inline-asm v_max3 here read the
@@ -186,18 +191,25 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, -1, 0x00020000);
     const int tile_stride_b = BKV * (int)ld * 2;
+    // One branch for the whole tile, the ragged case out of line: a taken branch costs the wave an instruction-buffer refill, and the
+    // common path of the tile loop should not contain any (see RT_RARE).
     auto stage = [&](int sl, int tix, bool clamp) {
       char* kb = smem + sl * 2 * TILE_B;
-      const int kv0 = tix * BKV;
+      if (RT_RARE(clamp)) {   // ragged last tile: rows past the end re-read row S-1 (masked later)
+        const int kv0 = tix * BKV;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        uint32_t off = soff[p];
-        if (clamp) {   // ragged last tile: rows past the end re-read row S-1 (masked later)
+        for (int p = 0; p < 4; ++p) {
           const int row_t = (wave * 4 + p) * 4 + srow;
-          off = ((uint32_t)(min(kv0 + row_t, S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
+          const uint32_t off = ((uint32_t)(min(kv0 + row_t, S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)soff[p], tix * tile_stride_b, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)soff[p], tix * tile_stride_b, 0, 0);
+        }
       }
     };
 
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       const float mxr = fmaxf(__builtin_bit_cast(float, xa), __builtin_bit_cast(float, xb)) * scale_log2;
       float alpha = 1.f;
       pend = false;
-      if (__any(mxr - m_run > RESCALE_THR)) {
+      if (RT_RARE(__any(mxr - m_run > RESCALE_THR))) {
         asm volatile("" ::: "memory");           // keep this rare block a real branch (not if-converted)
         const float m_new = fmaxf(m_run, mxr);
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0 on zeroed state
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       }
       return alpha;
     };
-    auto rescale_o = [&](float alpha) {
+    auto rescale_o = [&](float alpha) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) kA[ks] = kread(0, ks);
 #ifndef ATT_ABL_NODMA
-      if (t + 1 < te) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
+      if (RT_USUAL(t + 1 < te)) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
 #endif
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], s0, 0, 0, 0);
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       for (int ks = 0; ks < 3; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[ks], qf[ks], s1, 0, 0, 0);
 #pragma unroll
       for (int ks = 3; ks < 8; ++ks) kB[ks] = kread(1, ks);
-      if (ragged) mask_half(s0, 0);
+      if (RT_RARE(ragged)) mask_half(s0, 0);
       float mx0 = half_max(s0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       RT_SB();
       {
         const float alpha = decide(mx0, pend);
-        if (pend) rescale_o(alpha);
+        if (RT_RARE(pend)) rescale_o(alpha);
       }
       RT_SB();
       // ---- 3: rest of Sᵀ(h1) ∥ numerators of h0, k-step 0; Vᵀ fragments of (h0, k-step 0) come in
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vB[dt] = vread(0, 1, dt);
       numer8(s0, 1, p01);
-      if (ragged) mask_half(s1, 1);
+      if (RT_RARE(ragged)) mask_half(s1, 1);
       float mx1 = half_max(s1);
       RT_WEAVE(4, 2, 9)
       RT_PIN(p01); RT_PIN(l_run); RT_PIN(mx1);
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       RT_WEAVE(4, 2, 7)
       RT_PIN(p10); RT_PIN(l_run);
       RT_SB();
-      if (pend) rescale_o(alpha1);
+      if (RT_RARE(pend)) rescale_o(alpha1);
       RT_SB();
       // ---- 6: Oᵀ += Vᵀ(h1, k-step 0)·p10 ∥ numerators of h1 k-step 1
 #pragma unroll
