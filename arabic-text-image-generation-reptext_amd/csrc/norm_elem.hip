@@ -2,6 +2,7 @@
 // timestep/RoPE tables, Euler step, latent pack/unpack, casts. All loads/stores are 8–16 B per lane,
 // statistics in fp32. Math per SURVEY.md Appendix A.1/A.2/A.5/A.6 and PIPE:550-570,1109.
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -195,48 +196,62 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const void* __re
 // q/k RMSNorm(128) + RoPE in place. 16 lanes per 128-vector (8 elements = 4 rotation pairs each),
 // 4 vectors per wave. Grid covers B*S*H*2 vectors (q and k).
 // ---------------------------------------------------------------------------------------------------
+// A 16-lane group takes one token row and QK_HC heads of it (q and k: 2·QK_HC vectors of 128), so the row's cos/sin entries and
+// the norm weights are loaded once per 2·QK_HC vectors. Measured at 4608×24 heads: one vector per group 21.6 µs, QK_HC = 1 19.7 µs,
+// 2: 22.9, 4: 33 — the kernel lives on wave-level parallelism, longer per-lane chains lose more than the table bytes they save.
+constexpr int QK_HC = 1;
 __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
     bf16_t* __restrict__ buf, int64_t ld, int64_t stride_b, int64_t q_off, int64_t k_off,
     const bf16_t* __restrict__ wq_txt, const bf16_t* __restrict__ wk_txt, const bf16_t* __restrict__ wq_img,
     const bf16_t* __restrict__ wk_img, const float* __restrict__ cosv, const float* __restrict__ sinv, int B, int S,
     int T, int H, float eps) {
-  const int64_t vec = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // vector id
+  const int nchunk = (H + QK_HC - 1) / QK_HC;
+  const int64_t grp = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head chunk)
   const int sub = threadIdx.x & 15;
-  const int64_t nvec = (int64_t)B * S * H * 2;
-  if (vec >= nvec) return;   // whole 16-lane groups exit together; shuffles below stay within the group
-  const int isk = (int)(vec & 1);
-  int64_t t = vec >> 1;
-  const int h = (int)(t % H); t /= H;
-  const int s = (int)(t % S);
-  const int b = (int)(t / S);
-  bf16_t* p = buf + b * stride_b + (int64_t)s * ld + (isk ? k_off : q_off) + h * 128 + sub * 8;
-  const bf16_t* w = (s < T) ? (isk ? wk_txt : wq_txt) : (isk ? wk_img : wq_img);
-  const u32x4 u = *reinterpret_cast<const u32x4*>(p);
-  const u32x4 wu = *reinterpret_cast<const u32x4*>(w + sub * 8);
-  float x[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { x[2 * i] = bf16lo(u[i]); x[2 * i + 1] = bf16hi(u[i]); }
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+  if (grp >= (int64_t)B * S * nchunk) return;   // whole 16-lane groups exit together; shuffles below stay within the group
+  const int hc = (int)(grp % nchunk);
+  const int64_t row = grp / nchunk;
+  const int s = (int)(row % S);
+  const int b = (int)(row / S);
+  bf16_t* base = buf + b * stride_b + (int64_t)s * ld + sub * 8;
+  const bf16_t* wq = (s < T) ? wq_txt : wq_img;
+  const bf16_t* wk = (s < T) ? wk_txt : wk_img;
+  const u32x4 wuq = *reinterpret_cast<const u32x4*>(wq + sub * 8), wuk = *reinterpret_cast<const u32x4*>(wk + sub * 8);
   const float* cp = cosv + (int64_t)s * 128 + sub * 8;
   const float* sp = sinv + (int64_t)s * 128 + sub * 8;
   const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-  float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-  float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-  u32x4 o;
+  const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+  const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+  u32x4 u[2 * QK_HC];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = x[2 * i] * r * bf16lo(wu[i]);
-    const float bq = x[2 * i + 1] * r * bf16hi(wu[i]);
-    // out[2j] = a·cos[2j] − b·sin[2j] ; out[2j+1] = b·cos[2j+1] + a·sin[2j+1]
-    o[i] = pack_bf16x2(a * cs[2 * i] - bq * sn[2 * i], bq * cs[2 * i + 1] + a * sn[2 * i + 1]);
+  for (int v = 0; v < 2 * QK_HC; ++v) {
+    const int h = hc * QK_HC + (v >> 1);
+    u[v] = u32x4{0u, 0u, 0u, 0u};
+    if (h < H) u[v] = *reinterpret_cast<const u32x4*>(base + ((v & 1) ? k_off : q_off) + h * 128);
   }
-  *reinterpret_cast<u32x4*>(p) = o;
+#pragma unroll
+  for (int v = 0; v < 2 * QK_HC; ++v) {
+    const int h = hc * QK_HC + (v >> 1);
+    const u32x4 wu = (v & 1) ? wuk : wuq;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = bf16lo(u[v][i]); x[2 * i + 1] = bf16hi(u[v][i]); }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = x[2 * i] * r * bf16lo(wu[i]);
+      const float bq = x[2 * i + 1] * r * bf16hi(wu[i]);
+      o[i] = pack_bf16x2(a * cs[2 * i] - bq * sn[2 * i], bq * cs[2 * i + 1] + a * sn[2 * i + 1]);
+    }
+    if (h < H) *reinterpret_cast<u32x4*>(base + ((v & 1) ? k_off : q_off) + h * 128) = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -540,8 +555,8 @@ int rt_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t stride_b, int64_t q_off, i
   if (!RT_ALIGNED(buf, 16) || ld % 8 || stride_b % 8 || q_off % 8 || k_off % 8 || !RT_ALIGNED(cosv, 16) ||
       !RT_ALIGNED(sinv, 16) || !RT_ALIGNED(wq_img, 16) || !RT_ALIGNED(wk_img, 16))
     return RT_E_ALIGN;
-  const int64_t nvec = (int64_t)B * S * H * 2;
-  const int64_t blocks = (nvec + 15) / 16;
+  const int64_t ngrp = (int64_t)B * S * ((H + QK_HC - 1) / QK_HC);
+  const int64_t blocks = (ngrp + 15) / 16;
   if (blocks > 0x7fffffff) return RT_E_SHAPE;
   hipLaunchKernelGGL(qk_rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)buf, ld, stride_b, q_off, k_off, (const bf16_t*)wq_txt, (const bf16_t*)wk_txt,

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph"
 echo "[1] kernel trace + stats (bf16)"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -- $B > $OUT/bench_under_rocprof_bf16.json 2> $OUT/stats_bf16.err
 echo "[2] kernel trace + stats (fp8)";  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fp8 -- $B --precision fp8 > $OUT/bench_under_rocprof_fp8.json 2> $OUT/stats_fp8.err
 echo "[3] traffic passes (bf16)"
