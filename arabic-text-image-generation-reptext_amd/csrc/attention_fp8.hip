@@ -53,49 +53,52 @@ __global__ __launch_bounds__(256) void prep_qk_kernel(const bf16_t* __restrict__
                                                       const bf16_t* __restrict__ wk_img, const float* __restrict__ cosv,
                                                       const float* __restrict__ sinv, uint8_t* __restrict__ qk8, int B, int S, int T,
                                                       int H, float eps) {
-  const int64_t vec = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  // one 16-lane group per (row, head): q then k, so the row's cos/sin entries are loaded once for both (see qk_rmsnorm_rope_kernel)
+  const int64_t grp = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int sub = threadIdx.x & 15;
-  const int64_t nvec = (int64_t)B * S * H * 2;
-  if (vec >= nvec) return;
-  const int isk = (int)(vec & 1);
-  int64_t t = vec >> 1;
+  if (grp >= (int64_t)B * S * H) return;
+  int64_t t = grp;
   const int h = (int)(t % H); t /= H;
   const int s = (int)(t % S);
   const int b = (int)(t / S);
-  const bf16_t* p = buf + b * stride_b + (int64_t)s * ld + (isk ? k_off : q_off) + h * 128 + sub * 8;
-  const bf16_t* w = (s < T) ? (isk ? wk_txt : wq_txt) : (isk ? wk_img : wq_img);
-  const u32x4 u = *reinterpret_cast<const u32x4*>(p);
-  const u32x4 wu = *reinterpret_cast<const u32x4*>(w + sub * 8);
-  float x[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { x[2 * i] = bf16lo(u[i]); x[2 * i + 1] = bf16hi(u[i]); }
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
   const float* cp = cosv + (int64_t)s * 128 + sub * 8;
   const float* sp = sinv + (int64_t)s * 128 + sub * 8;
   const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
   const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
   const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-  float y[8];
+  const bf16_t* row = buf + b * stride_b + (int64_t)s * ld + h * 128 + sub * 8;
+  u32x4 uu[2] = {*reinterpret_cast<const u32x4*>(row + q_off), *reinterpret_cast<const u32x4*>(row + k_off)};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = x[2 * i] * r * bf16lo(wu[i]);
-    const float bq = x[2 * i + 1] * r * bf16hi(wu[i]);
-    y[2 * i] = sat448((a * cs[2 * i] - bq * sn[2 * i]) * QK_PRESCALE);
-    y[2 * i + 1] = sat448((bq * cs[2 * i + 1] + a * sn[2 * i + 1]) * QK_PRESCALE);
+  for (int isk = 0; isk < 2; ++isk) {
+    const bf16_t* w = (s < T) ? (isk ? wk_txt : wq_txt) : (isk ? wk_img : wq_img);
+    const u32x4 u = uu[isk];
+    const u32x4 wu = *reinterpret_cast<const u32x4*>(w + sub * 8);
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = bf16lo(u[i]); x[2 * i + 1] = bf16hi(u[i]); }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = x[2 * i] * r * bf16lo(wu[i]);
+      const float bq = x[2 * i + 1] * r * bf16hi(wu[i]);
+      y[2 * i] = sat448((a * cs[2 * i] - bq * sn[2 * i]) * QK_PRESCALE);
+      y[2 * i + 1] = sat448((bq * cs[2 * i + 1] + a * sn[2 * i + 1]) * QK_PRESCALE);
+    }
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
+    uint8_t* o = qk8 + ((int64_t)b * S + s) * (2 * H * 128) + (isk ? H * 128 : 0) + h * 128 + sub * 8;
+    *reinterpret_cast<u32x2*>(o) = u32x2{(uint32_t)lo, (uint32_t)hi};
   }
-  int lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
-  uint8_t* o = qk8 + ((int64_t)b * S + s) * (2 * H * 128) + (isk ? H * 128 : 0) + h * 128 + sub * 8;
-  *reinterpret_cast<u32x2*>(o) = u32x2{(uint32_t)lo, (uint32_t)hi};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -355,8 +358,8 @@ extern "C" int rt_attention_fp8_prep(const void* buf, int64_t ld, int64_t stride
   if (!RT_ALIGNED(buf, 16) || ld % 8 || stride_b % 8 || q_off % 8 || k_off % 8 || v_off % 8 || !RT_ALIGNED(cosv, 16) ||
       !RT_ALIGNED(sinv, 16) || !RT_ALIGNED(wq_img, 16) || !RT_ALIGNED(wk_img, 16) || !RT_ALIGNED(qk8, 16) || !RT_ALIGNED(vt8, 16))
     return RT_E_ALIGN;
-  const int64_t nvec = (int64_t)B * S * H * 2;
-  const int64_t blocks = (nvec + 15) / 16;
+  const int64_t ngrp = (int64_t)B * S * H;
+  const int64_t blocks = (ngrp + 15) / 16;
   if (blocks > 0x7fffffff) return RT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(prep_qk_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)buf, ld, stride_b, q_off, k_off,
