@@ -198,12 +198,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ void gn_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk, int G2) {
+// One workgroup of 1024 threads per batch entry: thread (seg, j) sums the partials k = seg, seg + nseg, ... of statistic j (independent
+// loads, up to nblk / nseg each), the nseg segment sums of a statistic are then added in segment order — a fixed order, run to run.
+// (The first version walked all nblk <= 1024 partials of a statistic in one thread: 75-250 us per call for a few KiB of data.)
+__global__ __launch_bounds__(1024) void gn_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk, int G2) {
+  __shared__ double seg_sum[1024];
   const int b = blockIdx.x;
-  for (int j = threadIdx.x; j < G2; j += blockDim.x) {
-    double acc = 0.0;
-    for (int k = 0; k < nblk; ++k) acc += part[((int64_t)b * nblk + k) * G2 + j];
-    stats[(int64_t)b * G2 + j] = acc;
+  const int nseg = blockDim.x / G2;              // host launches with G2 <= 1024 dividing... any G2 <= blockDim.x works (tail threads idle)
+  const int j = threadIdx.x % G2, seg = threadIdx.x / G2;
+  double acc = 0.0;
+  if (seg < nseg)
+    for (int k = seg; k < nblk; k += nseg) acc += part[((int64_t)b * nblk + k) * G2 + j];
+  seg_sum[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < G2) {
+    double tot = 0.0;
+    for (int sgm = 0; sgm < nseg; ++sgm) tot += seg_sum[sgm * G2 + threadIdx.x];
+    stats[(int64_t)b * G2 + threadIdx.x] = tot;
   }
 }
 
@@ -499,7 +510,8 @@ int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void
   double* stats = (double*)stats_ws;                       // [B][2G] final sums
   double* part = stats + (int64_t)B * 2 * G;               // [B][nblk][2G] workgroup partials
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, (const bf16_t*)x, part, B, H, W, C, G, ppb);
-  hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(64), 0, st, (const double*)part, stats, nblk, 2 * G);
+  if (2 * G > 1024) return RT_E_SHAPE;
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(1024), 0, st, (const double*)part, stats, nblk, 2 * G);
   const int64_t total = (int64_t)B * HW * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
                      (const double*)stats, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, eps, silu);
