@@ -201,8 +201,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 // One workgroup of 1024 threads per batch entry: thread (seg, j) sums the partials k = seg, seg + nseg, ... of statistic j (independent
 // loads, up to nblk / nseg each), the nseg segment sums of a statistic are then added in segment order — a fixed order, run to run.
 // (The first version walked all nblk <= 1024 partials of a statistic in one thread: 75-250 us per call for a few KiB of data.)
-__global__ __launch_bounds__(1024) void gn_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk, int G2) {
+__global__ __launch_bounds__(1024) void gn_reduce_kernel(const double* __restrict__ part, int nblk, int G2, float* __restrict__ mr,
+                                                          double cnt, float eps) {
   __shared__ double seg_sum[1024];
+  __shared__ double tot_s[1024];
   const int b = blockIdx.x;
   const int nseg = blockDim.x / G2;              // host launches with G2 <= 1024 dividing... any G2 <= blockDim.x works (tail threads idle)
   const int j = threadIdx.x % G2, seg = threadIdx.x / G2;
@@ -214,18 +216,26 @@ __global__ __launch_bounds__(1024) void gn_reduce_kernel(const double* __restric
   if (threadIdx.x < G2) {
     double tot = 0.0;
     for (int sgm = 0; sgm < nseg; ++sgm) tot += seg_sum[sgm * G2 + threadIdx.x];
-    stats[(int64_t)b * G2 + threadIdx.x] = tot;
+    tot_s[threadIdx.x] = tot;
+  }
+  __syncthreads();
+  // mean and 1/std of every group, once (gn_apply used to redo this fp64 arithmetic for every element)
+  if (threadIdx.x < G2 / 2) {
+    const double sm = tot_s[2 * threadIdx.x], sq = tot_s[2 * threadIdx.x + 1];
+    const double mean = sm / cnt;
+    const double var = sq / cnt - mean * mean;
+    mr[((int64_t)b * (G2 / 2) + threadIdx.x) * 2] = (float)mean;
+    mr[((int64_t)b * (G2 / 2) + threadIdx.x) * 2 + 1] = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
   }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                        const double* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                        const float* __restrict__ mr, const bf16_t* __restrict__ gamma,
                                                         const bf16_t* __restrict__ beta, int B, int H, int W, int C, int G,
-                                                        float eps, int silu) {
+                                                        int silu) {
   const int c8 = C / 8;
   const int64_t total = (int64_t)B * H * W * c8;
   const int cpg = C / G;
-  const double cnt = (double)H * W * cpg;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i % c8);
     int64_t p = i / c8;
@@ -245,11 +255,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int g = (chunk * 8 + 2 * j + e) / cpg;
-        const double sm = stats[((int64_t)b * G + g) * 2], sq = stats[((int64_t)b * G + g) * 2 + 1];
-        const double mean = sm / cnt;
-        const double var = sq / cnt - mean * mean;
-        const float rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
-        float t = (v[e] - (float)mean) * rstd * gm[e] + bt[e];
+        const float mean = mr[((int64_t)b * G + g) * 2], rstd = mr[((int64_t)b * G + g) * 2 + 1];
+        float t = (v[e] - mean) * rstd * gm[e] + bt[e];
         if (silu) t = silu_f(t);
         v[e] = t;
       }
@@ -507,14 +514,14 @@ int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void
   const int HW = H * W;
   const int ppb = gn_pix_per_block(HW);
   const int nblk = (HW + ppb - 1) / ppb;
-  double* stats = (double*)stats_ws;                       // [B][2G] final sums
-  double* part = stats + (int64_t)B * 2 * G;               // [B][nblk][2G] workgroup partials
+  float* mr = (float*)stats_ws;                            // [B][G][mean, 1/std] (in the first B*2G doubles of the workspace)
+  double* part = (double*)stats_ws + (int64_t)B * 2 * G;   // [B][nblk][2G] workgroup partials
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, (const bf16_t*)x, part, B, H, W, C, G, ppb);
   if (2 * G > 1024) return RT_E_SHAPE;
-  hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(1024), 0, st, (const double*)part, stats, nblk, 2 * G);
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(1024), 0, st, (const double*)part, nblk, 2 * G, mr, (double)HW * (C / G), eps);
   const int64_t total = (int64_t)B * HW * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
-                     (const double*)stats, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, eps, silu);
+                     (const float*)mr, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, silu);
   return rt_hip_status();
 }
 
