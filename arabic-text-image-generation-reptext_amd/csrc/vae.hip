@@ -173,16 +173,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   float se[8], qe[8];                                      // one partial per element of this thread's 8-channel chunk
 #pragma unroll
   for (int i = 0; i < 8; ++i) { se[i] = 0.f; qe[i] = 0.f; }
-  for (int p = p0 + threadIdx.x / c8; p < pend; p += pstep) {
-    const int yy = p / W, xx = p - yy * W;
-    const u32x4 u = *reinterpret_cast<const u32x4*>(x + (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + chunk * 8);
+  // four pixels per trip: the four 16-byte loads are in flight together (same per-thread summation order as one at a time)
+  int p = p0 + threadIdx.x / c8;
+  auto ld = [&](int pp) {
+    const int yy = pp / W, xx = pp - yy * W;
+    return *reinterpret_cast<const u32x4*>(x + (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + chunk * 8);
+  };
+  auto acc = [&](const u32x4 u) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a0 = bf16lo(u[i]), a1 = bf16hi(u[i]);
       se[2 * i] += a0; qe[2 * i] += a0 * a0;
       se[2 * i + 1] += a1; qe[2 * i + 1] += a1 * a1;
     }
+  };
+  for (; p + 3 * pstep < pend; p += 4 * pstep) {
+    const u32x4 u0 = ld(p), u1 = ld(p + pstep), u2 = ld(p + 2 * pstep), u3 = ld(p + 3 * pstep);
+    acc(u0); acc(u1); acc(u2); acc(u3);
   }
+  for (; p < pend; p += pstep) acc(ld(p));
 #pragma unroll
   for (int i = 0; i < 8; ++i) { lane_part[threadIdx.x][i] = se[i]; lane_part[threadIdx.x][8 + i] = qe[i]; }
   __syncthreads();
