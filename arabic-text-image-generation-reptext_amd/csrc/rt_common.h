@@ -31,6 +31,8 @@ __device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u <
 __device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x·sigmoid(x) on the transcendental unit (v_exp_f32, v_rcp_f32): 4 instructions instead of ~25; |rel err| < 3e-7 (1 ulp of rcp)
+__device__ __forceinline__ float silu_fast_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 // GELU tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))  == x * sigmoid(2u)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // x·sigmoid(2u), u = sqrt(2/pi)(x + 0.044715x³); exp and reciprocal on the transcendental unit (v_exp_f32, v_rcp_f32):

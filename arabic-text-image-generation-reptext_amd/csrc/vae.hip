@@ -242,15 +242,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                         const float* __restrict__ mr, const bf16_t* __restrict__ gamma,
                                                         const bf16_t* __restrict__ beta, int B, int H, int W, int C, int G,
                                                         int silu) {
+  // grid: x = 256-thread slices of one image row (W * C/8 chunks), y = (batch, row): one 32-bit division per thread instead of the
+  // three 64-bit ones of a flat index, and the row/batch indices are scalar
   const int c8 = C / 8;
-  const int64_t total = (int64_t)B * H * W * c8;
   const int cpg = C / G;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int chunk = (int)(i % c8);
-    int64_t p = i / c8;
-    const int xx = (int)(p % W); p /= W;
-    const int yy = (int)(p % H);
-    const int b = (int)(p / H);
+  const int yy = (int)blockIdx.y % H, b = (int)blockIdx.y / H;
+  {
+    const int ir = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (ir >= W * c8) return;
+    const int xx = ir / c8, chunk = ir - xx * c8;
     const int64_t off = (((int64_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + chunk * 8;
     const u32x4 u = *reinterpret_cast<const u32x4*>(x + off);
     const u32x4 gu = *reinterpret_cast<const u32x4*>(gamma + chunk * 8);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const int g = (chunk * 8 + 2 * j + e) / cpg;
         const float mean = mr[((int64_t)b * G + g) * 2], rstd = mr[((int64_t)b * G + g) * 2 + 1];
         float t = (v[e] - mean) * rstd * gm[e] + bt[e];
-        if (silu) t = silu_f(t);
+        if (silu) t = silu_fast_f(t);
         v[e] = t;
       }
       o[j] = pack_bf16x2(v[0], v[1]);
@@ -528,8 +528,8 @@ int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, (const bf16_t*)x, part, B, H, W, C, G, ppb);
   if (2 * G > 1024) return RT_E_SHAPE;
   hipLaunchKernelGGL(gn_reduce_kernel, dim3(B), dim3(1024), 0, st, (const double*)part, nblk, 2 * G, mr, (double)HW * (C / G), eps);
-  const int64_t total = (int64_t)B * HW * (C / 8);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+  if ((int64_t)B * H > 65535) return RT_E_SHAPE;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((W * (C / 8) + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
                      (const float*)mr, (const bf16_t*)gamma, (const bf16_t*)beta, B, H, W, C, G, silu);
   return rt_hip_status();
 }
