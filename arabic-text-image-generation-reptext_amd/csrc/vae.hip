@@ -10,6 +10,7 @@
 // The GEMM is M = B·Ho·Wo output pixels, N = Cout, K = taps·Cin with the same 256×256×64 tiling, LDS image and
 // swizzle as gemm_bf16.hip; a K-tile is 64 channels of one tap, so its A rows are 128-B runs of the input.
 #include "rt_common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -28,7 +29,14 @@ struct ConvArgs {
   int B, Hs, Ws, Ho, Wo, Cin, Cout, ks, stride, ups, out_f32;
 };
 
+// WNC = wave columns of the 8-wave workgroup: 4 -> 256x256 tile, waves 2(M) x 4(N), 128x64 each (the GEMM's arrangement);
+// 2 -> 256x128 tile, waves 4(M) x 2(N), 64x64 each — for layers with Cout <= 128 (the decoder's 1024x1024 stages), where the wide
+// tile left half of the waves without a single live output column.
+template <int WNC>
 __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a) {
+  constexpr int BN = 64 * WNC;                       // shadows the file-level 256
+  constexpr int MI = BM / (8 / WNC) / 16;            // 16-row fragments per wave: 8 or 4
+  constexpr int WP = BN / 64;                        // weight pieces (8 rows each) per wave: 4 or 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_m = (a.B * a.Ho * a.Wo + BM - 1) / BM;
   const int tn = blockIdx.x / tiles_m;
@@ -40,7 +48,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WNC, wn = wave % WNC;
   const int pad = a.ks >> 1;
   const int Wp = a.Ws + 2;
 
@@ -55,8 +63,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
     const int b = m / (a.Ho * a.Wo);
     const int r = m - b * a.Ho * a.Wo;
     pb[p] = b; py[p] = r / a.Wo; px[p] = r - py[p] * a.Wo;
-    const int wr = min(n0 + row, a.Cout - 1);
-    srcW[p] = a.w + (int64_t)wr * K + plc[p];
+    // weight rows: WP pieces of 8 rows per wave (8 waves x WP x 8 = BN rows), same chunk permutation (row & 15 pattern repeats)
+    const int wrow = wave * (8 * WP) + (p % WP) * 8 + (lane >> 3);
+    const int wr = min(n0 + wrow, a.Cout - 1);
+    srcW[p] = a.w + (int64_t)wr * K + (((lane & 7) ^ ((wrow >> 1) & 7)) * 8);
   }
   const int stage_off = wave * 32 * 128;
   auto stage = [&](int buf, int kt) {
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
       else { sy = ((py[p] + dy - pad) >> a.ups) + 1; sx = ((px[p] + dx - pad) >> a.ups) + 1; }
       const bf16_t* src = a.x + (((int64_t)pb[p] * (a.Hs + 2) + sy) * Wp + sx) * a.Cin + c0 + plc[p];
       __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + p * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(srcW[p] + k0), LDS_PTR(base + TILE_BYTES + p * 1024), 16, 0, 0);
+      if (p < WP) __builtin_amdgcn_global_load_lds(GLB_PTR(srcW[p] + k0), LDS_PTR(smem + buf * BUF_BYTES + TILE_BYTES + (wave * WP + p) * 1024), 16, 0, 0);
     }
   };
 
@@ -80,12 +90,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
   const int sw = (lane >> 1) & 7;
   const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
-  const int a_base = wm * 128 * 128;
+  const int a_base = wm * (MI * 16) * 128;
   const int w_base = TILE_BYTES + wn * 64 * 128;
 
-  f32x4 acc[8][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -102,13 +112,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int rd = kk ? rd1 : rd0;
-        bf16x8 wf[4], af[8];
+        bf16x8 wf[4], af[MI];
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(tb + w_base + j * 2048 + rd);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tb + a_base + i * 2048 + rd);
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tb + a_base + i * 2048 + rd);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
@@ -118,10 +128,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_nhwc_kernel(const ConvArgs a)
   }
 
   if (!wave_live) return;
-  const int mrow = m0 + wm * 128 + l15;
+  const int mrow = m0 + wm * (MI * 16) + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int m = mrow + i * 16;
     if (m >= M) continue;
     const int b = m / (a.Ho * a.Wo);
@@ -488,15 +498,19 @@ int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* r
   a.out_f32 = out_f32;
   const int64_t M = (int64_t)B * a.Ho * a.Wo;
   if (M > 0x7fffffff) return RT_E_SHAPE;
-  const int tiles = (int)((M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+  const bool narrow = Cout <= 128;                     // 256x128 tile: every wave has live columns
+  const int bn = narrow ? 128 : BN;
+  const int tiles = (int)((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nhwc_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    for (const void* f : {reinterpret_cast<const void*>(conv_nhwc_kernel<4>), reinterpret_cast<const void*>(conv_nhwc_kernel<2>)}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_nhwc_kernel, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, a);
+  if (narrow) hipLaunchKernelGGL(conv_nhwc_kernel<2>, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_nhwc_kernel<4>, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, a);
   return rt_hip_status();
 }
 
