@@ -584,7 +584,8 @@ class FluxControlNetPipeline:
             graph = torch.cuda.CUDAGraph()
             step_index = self.scheduler._step_index
             try:
-                with torch.cuda.graph(graph):
+                # thread-local capture mode: calls made by OTHER threads (RCCL's watchdog polling its events) do not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = self._denoise_eager(static[0], static[1], static[2], static[3], static[4], tvals, static[5 : 5 + nh], static[5 + nh :],
                                               guidance_scale, cn_scale, cn_steps, control_mode, None, callback_inputs, num_inference_steps, timesteps,
                                               _quiet=True)
