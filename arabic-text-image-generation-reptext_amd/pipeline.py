@@ -93,11 +93,13 @@ class _Progress:
             self.bar.update(n)
 
 
-# RT_OVERLAP_TOWER=1 runs the ControlNet tower on a side stream next to the transformer (see _denoise). Bitwise neutral and
-# measured at -1 % per image on MI355X (2.119 / 2.138 s vs 2.150 / 2.154 s): the idle CUs of a 27/32-full round are too few
-# for the tower's 256x256 tiles to use well. Off by default, which also keeps every kernel alone on the chip for the
-# per-kernel timings of bench.py's roofline pass and the rocprof summaries.
-OVERLAP_TOWER = os.environ.get("RT_OVERLAP_TOWER", "0") == "1"
+# The ControlNet tower runs on a side stream next to the transformer (see _denoise_eager): within a step the two chains are
+# independent except that transformer block i reads tower sample i // 4. Bitwise neutral (test_tower_stream_overlap_is_bitwise_
+# neutral). Measured on MI355X: -0.5 % per image with the eager loop, -1.1 % when the loop is replayed from its hipGraph (2.105-2.110
+# vs 2.125-2.137 s, alternating runs on one box: the fork/join is then part of the graph instead of host-side event calls). On by
+# default (RT_OVERLAP_TOWER=0 turns it off); bench.py's roofline pass and the rocprof summaries run with it off so that every kernel
+# is alone on the chip when it is timed.
+OVERLAP_TOWER = os.environ.get("RT_OVERLAP_TOWER", "1") == "1"
 # RT_GRAPH=1 (default): the denoising loop of a call signature seen before is captured ONCE into a hipGraph (every kernel of the
 # 28 steps, ~7 000 nodes, host scalars baked in) and replayed for later calls with the same signature: bitwise the eager result,
 # the host returns after ~5 ms instead of enqueueing ~13 000 launches, the GPU loses the launch bubbles (-0.7 % per image).
@@ -552,7 +554,7 @@ class FluxControlNetPipeline:
                  cn_scale, cn_steps, control_mode, callback, callback_inputs, num_inference_steps):
         """Eager loop, or the replay of its captured hipGraph when this exact call signature has been seen before (GRAPH_CAPTURE)."""
         tvals = timesteps.to(torch.float32).cpu().tolist()                 # host copies: no per-step device sync
-        use_graph = (GRAPH_CAPTURE and getattr(self, "capture_graphs", True) and callback is None and latents.is_cuda and not OVERLAP_TOWER
+        use_graph = (GRAPH_CAPTURE and getattr(self, "capture_graphs", True) and callback is None and latents.is_cuda
                      and not self.interrupt and isinstance(self.controlnet, (FluxControlNetModel, type(None)))
                      and (control_mode is None) and self.joint_attention_kwargs is None)
         if not use_graph:
@@ -564,7 +566,7 @@ class FluxControlNetPipeline:
                         bool(getattr(m, "_fp8_attention", False))) for m in (self.transformer, self.controlnet) if m is not None)
         key = (sig(latents), sig(prompt_embeds), sig(pooled), sig(text_ids), sig(image_ids), tuple(sig(h) for h in hints), tuple(sig(m) for m in masks),
                tuple(tvals), tuple(self.scheduler.sigmas.tolist()), float(guidance_scale), repr(cn_scale), int(cn_steps), int(num_inference_steps),
-               str(latents.device), models, bool(_mm.REF_BF16_SCALARS), bool(_mm.RESIDUAL_F32))
+               str(latents.device), models, bool(_mm.REF_BF16_SCALARS), bool(_mm.RESIDUAL_F32), bool(OVERLAP_TOWER))
         cache = self.__dict__.setdefault("_graph_cache", {})
         ent = cache.get(key)
         if ent is None:                                      # first sight of this signature: eager (and warm), remember it

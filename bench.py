@@ -404,10 +404,12 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline_pass:
-        pipe.capture_graphs = False              # per-launch events need the eager loop
+        import reptext_amd.pipeline as _pl
+        pipe.capture_graphs = False              # per-launch events need the eager loop ...
+        _ov, _pl.OVERLAP_TOWER = _pl.OVERLAP_TOWER, False          # ... with every kernel alone on the chip (no tower beside the transformer)
         with GemmTimer(ops) as gt:
             one_pass(10 ** 6)
-        pipe.capture_graphs = not args.no_graph
+        pipe.capture_graphs, _pl.OVERLAP_TOWER = not args.no_graph, _ov
         if args.precision == "bf16":
             n_launch, fl, sec = gt.result()
             peak, kname, tkey = 2500.0, "gemm_pp_kernel<bf16> (rt_gemm_bf16)", "gemm"
@@ -449,7 +451,8 @@ def main():
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU on rank 0, denoise loop + VAE decode to uint8, random-init weights; "
                                    f"tower blocks evaluated {n_tower} of {cfg_c['num_layers']} (the last sample is never read, Q5)",
                        "global_batch": G, "conditioning": "shared prompt/hint/mask" if args.shared_prompt else "one prompt, hint and mask per image", "parallelism": f"batch-shard x{world}, one broadcast" + (f" ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else ""),
-                       "launch": "eager (one ctypes launch per kernel)" if args.no_graph else f"denoise loop replayed from one hipGraph per call signature ({n_pre} untimed passes: eager, then capture)"},
+                       "launch": ("eager (one ctypes launch per kernel)" if args.no_graph else f"denoise loop replayed from one hipGraph per call signature ({n_pre} untimed passes: eager, then capture)")
+                                 + ("; ControlNet tower on a side stream beside the transformer" if os.environ.get("RT_OVERLAP_TOWER", "1") == "1" else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.depth_scale != 1.0:

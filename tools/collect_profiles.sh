@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export RT_OVERLAP_TOWER=0    # rocprof passes: every kernel alone on the chip (the bench lines of step 6 run the default, tower beside the transformer)
 B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph"
 echo "[1] kernel trace + stats (bf16)"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -- $B > $OUT/bench_under_rocprof_bf16.json 2> $OUT/stats_bf16.err
 echo "[2] kernel trace + stats (fp8)";  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fp8 -- $B --precision fp8 > $OUT/bench_under_rocprof_fp8.json 2> $OUT/stats_fp8.err
@@ -36,6 +37,7 @@ for d in stats_bf16 stats_fp8; do
 done
 echo "[6] bench lines"
 cd $R
+unset RT_OVERLAP_TOWER
 python3 bench.py > $OUT/bench_c2_bf16.json 2> $OUT/bench_c2_bf16.err
 python3 bench.py --no-cpu-baseline --precision fp8 > $OUT/bench_c2_fp8.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --batch-per-gpu 4 --steps 2 --warmup 1 > $OUT/bench_c3_batch4_bf16.json 2>/dev/null
