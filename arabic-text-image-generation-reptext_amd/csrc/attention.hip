@@ -277,21 +277,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     // numerators of 8 keys (one k-step of Oᵀ += Vᵀ·Pᵀ): registers 8·s2 .. 8·s2+7 of a half
     auto numer8 = [&](const f32x16& s, int s2, bf16x8& pf) {
       float ps = 0.f;
-#ifdef ATT_ABL_NOSOFT
-      pf = __builtin_bit_cast(bf16x8, f32x4{s[8 * s2], s[8 * s2 + 1], s[8 * s2 + 2], s[8 * s2 + 3]});
-      ps = s[8 * s2 + 4];
-#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-#ifdef ATT_ABL_NOEXP
-        const float p = __builtin_fmaf(s[8 * s2 + j], scale_log2, -m_run);
-#else
         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[8 * s2 + j], scale_log2, -m_run));
-#endif
         ps += p;
         pf[j] = (__bf16)p;
       }
-#endif
       l_run += ps;
     };
 
@@ -299,16 +290,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
 // Opaque use+def: the value must exist HERE (keeps the optimiser from sinking a step's vector work below a later branch)
 #define RT_PIN(v) asm volatile("" : "+v"(v))
 // n groups of { 1 MFMA, nds LDS reads, nva vector/transcendental ops }
-#ifdef ATT_EXP_NOWEAVE
-#define RT_WEAVE(n, nds, nva)
-#else
 #define RT_WEAVE(n, nds, nva)                                          \
   _Pragma("unroll") for (int w_ = 0; w_ < (n); ++w_) {                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
     if ((nds) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (nds), 0); \
     if ((nva) > 0) __builtin_amdgcn_sched_group_barrier(0x402, (nva), 0); \
   }
-#endif
 
     auto tile = [&](auto slot_c, int t) {
       constexpr int SLOT = decltype(slot_c)::value;
@@ -317,14 +304,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       // stages is (its rows are clamped) / there is no next tile in this run
       const bool ragged = (t + 1) * BKV > S;
       auto kread = [&](int h, int ks) -> bf16x8 {
-#ifdef ATT_ABL_NOLDS
-        return qf[(ks + h) & 7];
-#endif
         return *(const __attribute__((address_space(3))) bf16x8*)(kp[ks] + SB + h * 8192); };
       auto vread = [&](int h, int s2, int dt) -> bf16x8 {
-#ifdef ATT_ABL_NOLDS
-        return qf[(dt + 2 * s2 + h) & 7];
-#endif
         const s16x4 lo = tr_read(vp[0][dt] + SB + h * 8192 + s2 * 4096);
         const s16x4 hi = tr_read(vp[1][dt] + SB + h * 8192 + s2 * 4096);
         return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -335,9 +316,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
           if (t * BKV + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hh >= S) s[r] = -INFINITY;
       };
       rt_dma_barrier();                          // tile t landed (every wave's vmcnt(0), then the barrier); the other slot is free
-#ifdef ATT_EXP_PRIO
-      __builtin_amdgcn_s_setprio(ATT_EXP_PRIO);
-#endif
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -347,9 +325,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       // ---- 1: Sᵀ(h0) = K[0:32]·Qᵀ (8 MFMAs) beside the LDS-DMA issue of tile t+1 and the first reads of h1
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) kA[ks] = kread(0, ks);
-#ifndef ATT_ABL_NODMA
       if (RT_USUAL(t + 1 < te)) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
-#endif
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], s0, 0, 0, 0);
 #pragma unroll
@@ -438,9 +414,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
 
     const int qrow = q0 + wave * 32 + l31;
     const bool whole = (tb == 0 && te == ntiles);
-#ifdef ATT_ABL_NOCOMBINE
-    if (!whole) continue;
-#endif
     if (!whole) {
       // ---- partial: write (Oᵀ, m, l) of this run through to memory, take a ticket, last ticket combines the item
       const int ritem = item - (cut.start + cut.nfull);            // index among the split items of this group

@@ -371,19 +371,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
 
   const int mrow = m0 + wm * 128 + l15;
   const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
-#ifdef RT_GEMM_ABL_NOEPI     // timing-only build (tools): keep the accumulators alive, skip the epilogue
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.f) reinterpret_cast<float*>(g.C)[0] = sacc;
-  }
-#else
   if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);
   else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc, G.wide_store != 0);
-#endif
 }
 
 }  // namespace

@@ -209,6 +209,9 @@ class Workspace:
 
 
 _WS_CACHE = {}
+# While a hipGraph of the loop is being captured (pipeline._denoise) every Workspace handed out is also appended here: the graph
+# bakes in their device pointers, so its cache entry must OWN them — this cache may evict or replace an entry at any time.
+CAPTURE_KEEP: Optional[list] = None
 
 
 def workspace(B, T, N, d, device, need_single, tag: str = "") -> Workspace:
@@ -220,6 +223,8 @@ def workspace(B, T, N, d, device, need_single, tag: str = "") -> Workspace:
             _WS_CACHE.clear()
         ws = Workspace(B, T, N, d, device, need_single)
         _WS_CACHE[key] = ws
+    if CAPTURE_KEEP is not None:
+        CAPTURE_KEEP.append(ws)
     return ws
 
 

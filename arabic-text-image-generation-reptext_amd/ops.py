@@ -287,12 +287,15 @@ def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, w
 
 
 _ATTN_WS = {}
+CAPTURE_KEEP: Optional[list] = None      # see mmdit.CAPTURE_KEEP: workspaces a graph under capture refers to
 
 
 def _attention_workspace(B: int, S: int, H: int, device) -> Optional[torch.Tensor]:
     """Workspace of rt_attention_fwd's key-split tail (ticket counters + partial records), one per (shape, device, stream):
     two streams may run attention of the same shape at once (tower beside transformer). Zeroed once — the kernel leaves the
-    counters zero. None when this shape splits nothing."""
+    counters zero. None when this shape splits nothing. A workspace first requested while a stream capture is running is
+    zeroed by a memset NODE of that graph (replayed with it); should the capture be abandoned, pipeline._denoise drops the
+    entries it created (drop_attention_workspaces), so a never-executed zero fill cannot be picked up later."""
     key = (B, S, H, str(device), _stream())
     ws = _ATTN_WS.get(key, False)
     if ws is False:
@@ -301,7 +304,14 @@ def _attention_workspace(B: int, S: int, H: int, device) -> Optional[torch.Tenso
         if len(_ATTN_WS) > 16:
             _ATTN_WS.clear()
         _ATTN_WS[key] = ws
+    if CAPTURE_KEEP is not None and ws is not None:
+        CAPTURE_KEEP.append(ws)
     return ws
+
+
+def drop_attention_workspaces(keys) -> None:
+    for k in list(keys):
+        _ATTN_WS.pop(k, None)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, H: int, scale: Optional[float] = None,

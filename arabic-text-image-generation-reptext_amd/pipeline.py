@@ -561,12 +561,13 @@ class FluxControlNetPipeline:
             return self._denoise_eager(latents, prompt_embeds, pooled, text_ids, image_ids, tvals, hints, masks, guidance_scale, cn_scale,
                                        cn_steps, control_mode, callback, callback_inputs, num_inference_steps, timesteps)
         from . import mmdit as _mm
+        _mm.reference_bf16_scalars(self.reference_bf16_scalars)      # the module switch follows THIS pipeline before the key is built
         sig = lambda t: (tuple(t.shape), str(t.dtype), tuple(t.stride()))
         models = tuple((id(m), id(m._ensure_plans()), id(getattr(m, "_cx_pad", None)), bool(getattr(m, "_fp8_linears", False)),
                         bool(getattr(m, "_fp8_attention", False))) for m in (self.transformer, self.controlnet) if m is not None)
         key = (sig(latents), sig(prompt_embeds), sig(pooled), sig(text_ids), sig(image_ids), tuple(sig(h) for h in hints), tuple(sig(m) for m in masks),
                tuple(tvals), tuple(self.scheduler.sigmas.tolist()), float(guidance_scale), repr(cn_scale), int(cn_steps), int(num_inference_steps),
-               str(latents.device), models, bool(_mm.REF_BF16_SCALARS), bool(_mm.RESIDUAL_F32), bool(OVERLAP_TOWER))
+               str(latents.device), models, bool(self.reference_bf16_scalars), bool(_mm.RESIDUAL_F32), bool(OVERLAP_TOWER))
         cache = self.__dict__.setdefault("_graph_cache", {})
         ent = cache.get(key)
         if ent is None:                                      # first sight of this signature: eager (and warm), remember it
@@ -585,6 +586,12 @@ class FluxControlNetPipeline:
             keep = [m._ensure_plans() for m in (self.transformer, self.controlnet) if m is not None] + [getattr(self.controlnet, "_cx_pad", None)]
             graph = torch.cuda.CUDAGraph()
             step_index = self.scheduler._step_index
+            # The graph bakes in the device pointers of every buffer the loop touches. Buffers that live in caches which may evict or
+            # replace them later (activation workspaces, attention key-split workspaces, tower sample buffers, rope tables) are
+            # recorded while the capture runs and OWNED by the graph's entry: a replay can never write into memory that was handed
+            # back to the allocator (tests: test_graphs_of_two_shapes_keep_their_buffers).
+            attn_keys = set(ops._ATTN_WS)
+            _mm.CAPTURE_KEEP, ops.CAPTURE_KEEP = keep, keep
             try:
                 # thread-local capture mode: calls made by OTHER threads (RCCL's watchdog polling its events) do not invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -596,10 +603,15 @@ class FluxControlNetPipeline:
                 import sys
                 print(f"[reptext_amd] hipGraph capture of the denoise loop failed ({type(e).__name__}: {e}); staying eager", file=sys.stderr, flush=True)
                 cache[key] = "failed"
+                _mm.CAPTURE_KEEP = ops.CAPTURE_KEEP = None
+                ops.drop_attention_workspaces(set(ops._ATTN_WS) - attn_keys)     # their zero fill was recorded, never executed
                 torch.cuda.synchronize()
                 self.scheduler._step_index = step_index
                 return self._denoise_eager(latents, prompt_embeds, pooled, text_ids, image_ids, tvals, hints, masks, guidance_scale, cn_scale,
                                            cn_steps, control_mode, None, callback_inputs, num_inference_steps, timesteps)
+            _mm.CAPTURE_KEEP = ops.CAPTURE_KEEP = None
+            keep.append(getattr(self, "_sample_cache", None))
+            keep.extend(dict(m._rope_cache) for m in (self.transformer, self.controlnet) if m is not None and hasattr(m, "_rope_cache"))
             self.scheduler._step_index = step_index
             ent = cache[key] = {"graph": graph, "static": static, "out": out, "out32": out32, "keep": keep}
         for dst, src in zip(ent["static"], ins):
@@ -656,7 +668,7 @@ class FluxControlNetPipeline:
         # sample buffers and the transformer waits, block by block, on the event of the sample it needs. At batch 1 most
         # launches fill only 27/32 of their last round of workgroups (216 GEMM tiles on 256 CUs, 864 attention workgroups on
         # 512 slots); two independent chains in flight fill some of those holes. Results are bitwise those of the serial order.
-        # Opt-in (OVERLAP_TOWER): the measured gain is 1 %.
+        # On by default (OVERLAP_TOWER; RT_OVERLAP_TOWER=0 turns it off): -0.5 % eager, -1.1 % inside the captured graph.
         overlap = (OVERLAP_TOWER and fused_cn and tab_c is not None and device.type == "cuda"
                    and len(self.controlnet.single_transformer_blocks) == 0)
         if overlap:

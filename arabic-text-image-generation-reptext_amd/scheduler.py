@@ -53,19 +53,20 @@ class FlowMatchEulerDiscreteScheduler:
         cfg = self.config
         if cfg.use_dynamic_shifting and mu is None:
             raise ValueError("`mu` must be passed when `use_dynamic_shifting` is set to be `True`")
-        if not cfg.use_dynamic_shifting and sigmas is None and timesteps is None:
-            # diffusers derives the default grid of this branch from sigma_min/sigma_max that its constructor has ALREADY passed
-            # through the static shift; that detail cannot be checked offline and FLUX.1 never takes the branch (its scheduler
-            # config sets use_dynamic_shifting=True) — refuse rather than return a schedule that may differ.
-            raise ValueError("FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=False): pass explicit `sigmas` or `timesteps`; "
-                             "the default sigma grid of the static-shift branch is not reproduced by this build")
         if sigmas is None:
             if timesteps is not None:
                 s = np.asarray(timesteps, dtype=np.float32) / cfg.num_train_timesteps
             else:
                 if num_inference_steps is None:
                     raise ValueError("pass num_inference_steps, sigmas or timesteps")
+                # diffusers takes the grid's end points from the sigma table its constructor built — which, without dynamic
+                # shifting, has ALREADY been passed through the static shift (sigma_max stays 1, sigma_min becomes
+                # shift·s/(1+(shift-1)·s) at s = 1/num_train_timesteps) — and then applies the shift to the grid once more below.
+                # Restated from knowledge of diffusers 0.36 (parity unpinned: the package is absent); FLUX.1's scheduler config
+                # sets use_dynamic_shifting=True and never takes this branch.
                 smax, smin = 1.0, 1.0 / cfg.num_train_timesteps
+                if not cfg.use_dynamic_shifting:
+                    smin = cfg.shift * smin / (1 + (cfg.shift - 1) * smin)
                 t = np.linspace(smax * cfg.num_train_timesteps, smin * cfg.num_train_timesteps, num_inference_steps)
                 s = (t / cfg.num_train_timesteps).astype(np.float32)
         else:

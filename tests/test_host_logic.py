@@ -322,7 +322,7 @@ def test_pipeline_from_pretrained_reads_model_index(tmp_path, monkeypatch):
         FluxControlNetPipeline.from_pretrained("black-forest-labs/FLUX.1-dev", controlnet=pipe.controlnet)
 
 
-def test_reference_bf16_scalar_mode_and_static_shift_guard():
+def test_reference_bf16_scalar_mode_and_static_shift_grid():
     """ADVICE round 1 (low): the reference's bf16 run rounds t, t/1000 and guidance·1000 to bf16 (PIPE:1025,1048; CN:282-284);
     the default path keeps them exact. Both modes exist in the pipeline and in the oracle and agree on the values."""
     from reptext_amd import mmdit
@@ -341,9 +341,13 @@ def test_reference_bf16_scalar_mode_and_static_shift_guard():
     pipe.reference_bf16_scalars = False
     pipe._model_timestep(1.0)
     assert mmdit.REF_BF16_SCALARS is False
-    # static-shift branch: explicit sigmas work, the unverifiable default grid is refused
+    # static-shift branch (diffusers' default scheduler config): explicit sigmas, and the default grid — linspace between the
+    # ALREADY shifted end points of the constructor's table, shifted once more (closed form; parity unpinned, diffusers absent)
     s = FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=False, shift=3.0)
     s.set_timesteps(sigmas=[1.0, 0.5])
     assert s.sigmas.tolist() == pytest.approx([1.0, 0.75, 0.0])
-    with pytest.raises(ValueError, match="static-shift"):
-        s.set_timesteps(4)
+    s.set_timesteps(4)
+    sh = lambda x: 3.0 * x / (1 + 2.0 * x)
+    grid = np.linspace(1000.0, sh(1e-3) * 1000.0, 4) / 1000.0
+    assert s.sigmas.tolist() == pytest.approx([sh(g) for g in grid] + [0.0], rel=1e-6)
+    assert s.timesteps.tolist() == pytest.approx([1000 * sh(g) for g in grid], rel=1e-6) and s.num_inference_steps == 4

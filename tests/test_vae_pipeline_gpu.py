@@ -427,6 +427,65 @@ def test_denoise_loop_graph_replay_is_bitwise_the_eager_loop(vae_pair, gpu):
     assert torch.equal(out2, pipe(**a, **two).images)
 
 
+def test_graphs_of_two_shapes_keep_their_buffers(vae_pair, gpu):
+    """ADVICE round 2 (high + medium). A captured loop bakes in device pointers; the caches those buffers came from (tower sample
+    buffers keyed by shape, mmdit._WS_CACHE, ops._ATTN_WS, rope tables) may evict them while the graph lives. Sequence
+    A, A(capture), B, B(capture) replaces the sample cache; then every cache is cleared and the freed sizes are re-allocated as
+    canaries before both graphs replay: outputs must equal the eager loop bit for bit and no canary byte may change.
+    Also: toggling `reference_bf16_scalars` between calls of one shape must never replay the other mode's graph."""
+    import reptext_amd.pipeline as P
+    from reptext_amd import mmdit, ops
+    from reptext_amd.controlnet import FluxControlNetModel
+    from reptext_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from reptext_amd.transformer import FluxTransformer2DModel
+
+    _, vae = vae_pair
+    tr = FluxTransformer2DModel(**SMALL_T, device=gpu, dtype=torch.bfloat16).random_init_(81)
+    cn = FluxControlNetModel(**SMALL_CN, device=gpu, dtype=torch.bfloat16).random_init_(82)
+    pipe = P.FluxControlNetPipeline(FlowMatchEulerDiscreteScheduler(), vae, None, None, None, None, tr, cn)
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(10)
+    r = lambda *s: torch.randn(*s, generator=g).to(gpu, torch.bfloat16)
+
+    def inputs(n):
+        return dict(prompt_embeds=r(1, 64, 256), pooled_prompt_embeds=r(1, 64), control_image=[r(1, n, 128)], latents=r(1, n, 64))
+
+    fa = dict(height=256, width=256, num_inference_steps=2, guidance_scale=3.5, controlnet_conditioning_step=2, output_type="latent")
+    fb = dict(fa, width=384)
+    a1, a2, b1, b2 = inputs(256), inputs(256), inputs(384), inputs(384)
+    pipe.capture_graphs = False
+    ref = {k: pipe(**i, **f).images.clone() for k, (i, f) in dict(a1=(a1, fa), a2=(a2, fa), b1=(b1, fb), b2=(b2, fb)).items()}
+    pipe.reference_bf16_scalars = True
+    ref16 = pipe(**a1, **fa).images.clone()
+    pipe.reference_bf16_scalars = False
+    assert not torch.equal(ref16, ref["a1"])
+    pipe.capture_graphs = True
+    assert torch.equal(pipe(**a1, **fa).images, ref["a1"])          # A: eager, remembered
+    assert torch.equal(pipe(**a1, **fa).images, ref["a1"])          # A: captured
+    assert torch.equal(pipe(**b1, **fb).images, ref["b1"])          # B: eager — replaces the shape-keyed sample cache
+    assert torch.equal(pipe(**b1, **fb).images, ref["b1"])          # B: captured
+    assert sum(isinstance(v, dict) for v in pipe._graph_cache.values()) == 2
+    # evict everything the graphs' buffers were cached in, then grab the freed memory
+    pipe._sample_cache = None
+    mmdit._WS_CACHE.clear()
+    ops._ATTN_WS.clear()
+    tr._rope_cache.clear(); cn._rope_cache.clear()
+    torch.cuda.synchronize()
+    sizes = [256 * 64 * 2, 320 * 512 * 2, 320 * 512 * 4, 320 * 1536 * 2, 320 * 2048 * 2, 320 * 3584 * 2, 448 * 512 * 4, 448 * 3584 * 2, 1 << 20, 8 << 20]
+    canaries = [torch.full((n,), 0x5A, device=gpu, dtype=torch.uint8) for n in sizes for _ in range(6)]
+    for k, (i, f) in dict(a2=(a2, fa), b2=(b2, fb), a1=(a1, fa), b1=(b1, fb)).items():
+        assert torch.equal(pipe(**i, **f).images, ref[k]), k         # replays on buffers the graph entries own
+    torch.cuda.synchronize()
+    assert all(bool((c == 0x5A).all()) for c in canaries)
+    # mode toggle on a shape whose fp32-scalar graph exists: eager (new key), then its own graph; the old graph still serves the old mode
+    pipe.reference_bf16_scalars = True
+    assert torch.equal(pipe(**a1, **fa).images, ref16)
+    assert torch.equal(pipe(**a1, **fa).images, ref16)
+    pipe.reference_bf16_scalars = False
+    assert torch.equal(pipe(**a1, **fa).images, ref["a1"])
+    assert torch.equal(pipe(**a1, **fa).images, ref["a1"])
+
+
 def test_pipeline_fp8_linears(vae_pair, gpu):
     """Config-5 precision through the whole loop (C1 shape, 4 steps, masked tower): latents vs the fp32 oracle and vs the oracle
     with the same e4m3 quantisation points; the GPU must sit on that run's floor."""

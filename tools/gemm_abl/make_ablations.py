@@ -21,7 +21,10 @@ def rep(old, new, where="tail"):
         head = src
 
 
-# the epilogue ablation is built into the kernel source: -DRT_GEMM_ABL_NOEPI (mapped from ABL_NOEPI below)
+# the epilogue ablation lives in the generated copy only (the product kernel carries no timing-only switches)
+rep("  if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);\n",
+    "#ifdef ABL_NOEPI\n  { float sacc = 0.f;\n    _Pragma(\"unroll\") for (int i = 0; i < 8; ++i) _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];\n"
+    "    if (sacc == 12345.f) reinterpret_cast<float*>(g.C)[0] = sacc; }\n  if (false)\n#endif\n  if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);\n")
 rep("  auto issue = [&](int part, int buf, int koff) {                        // koff in BYTES along the row",
     "  auto issue = [&](int part, int buf, int koff) {\n#ifdef ABL_NODMA\n    if (koff != 0) return;\n#endif")
 rep("#define RT_READ_A(ah)                                                                                             \\\n  _Pragma(\"unroll\") for (int i = 0; i < 4; ++i) {",
@@ -37,7 +40,7 @@ rep("    __builtin_amdgcn_s_setprio(1);                                         
     "    __builtin_amdgcn_s_setprio(1);                                                                                \\\n    if (ABL_MFMA_ON) { if constexpr (FP8) {")
 rep("                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \\\n    }                                                                                                             \\",
     "                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \\\n    } }                                                                                                           \\")
-head = head.replace("namespace {\n", "namespace {\n#ifdef ABL_NOEPI\n#define RT_GEMM_ABL_NOEPI 1\n#endif\n#ifdef ABL_NOMFMA\n#define ABL_MFMA_ON (nk < 0)\n#else\n#define ABL_MFMA_ON true\n#endif\n", 1)
+head = head.replace("namespace {\n", "namespace {\n#ifdef ABL_NOMFMA\n#define ABL_MFMA_ON (nk < 0)\n#else\n#define ABL_MFMA_ON true\n#endif\n", 1)
 open(os.path.join(here, "gemm_abl.hip"), "w").write(head + tail)
 variants = ["BASE", "NOEPI", "NODMA", "NOLDS", "NOBAR", "NOMFMA", "NOEPI -DABL_NODMA -DABL_NOLDS -DABL_NOBAR", "NODMA -DABL_NOLDS", "NOLDS -DABL_NOBAR -DABL_NODMA"]
 for v in variants:
