@@ -174,3 +174,25 @@ def test_oracle_primitives_match_torch_functional():
     assert torch.allclose(orc.apply_rope(xr, cos, sin), xr * cos[None, :, None, :] + rot * sin[None, :, None, :], atol=1e-6)
     # each RoPE frequency appears twice, consecutively (repeat_interleave, CN:316-317 / A.5)
     assert torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])
+
+
+def test_streamed_params_feed_the_oracle_identically():
+    """oracle/streamed.py: weights fetched one tensor at a time from another state dict (bf16, as the GPU models hold them)
+    give the oracle bit-identical results to a resident fp32 dict of the same values; config1_case is BASELINE configs[0]."""
+    import pytest
+
+    from oracle.streamed import StreamedParams, config1_case, config1_oracle
+
+    cfg_t = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=2, attention_head_dim=128, num_attention_heads=2,
+                 joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    cfg_c = dict(cfg_t, num_single_layers=0, extra_condition_channels=64)
+    tp, cp = orc.init_mmdit_params(cfg_t, 3), orc.init_mmdit_params(cfg_c, 4, controlnet=True)
+    case = config1_case(T=32, joint_dim=64, pooled_dim=32)
+    assert case["N"] == 256 and case["sigmas"].tolist() == pytest.approx([1.0, 0.622459, 0.0], abs=1e-6)
+    assert 0 < float(case["region_mask"].sum()) < case["N"]
+    ref = config1_oracle(tp, cfg_t, cp, cfg_c, case)
+    sp_t = StreamedParams({k: v.to(torch.bfloat16) for k, v in tp.items()})
+    sp_c = StreamedParams({k: v.to(torch.bfloat16) for k, v in cp.items()})
+    got = config1_oracle(sp_t, cfg_t, sp_c, cfg_c, case)
+    assert torch.equal(got, ref) and sp_t.bytes_streamed > 0 and len(sp_t) == len(tp) and "x_embedder.weight" in sp_t
+    assert sp_t.get("no.such.bias") is None
