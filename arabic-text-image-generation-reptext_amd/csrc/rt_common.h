@@ -89,3 +89,12 @@ __device__ __forceinline__ void rt_dma_barrier() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
+
+// Barrier that orders LDS traffic only (ds_write -> barrier -> ds_read by other waves) and leaves LDS-DMA / global loads in
+// flight: __syncthreads()'s fence also waits for every pending vector-memory operation — it drains an LDS-DMA issued for a LATER
+// tile — while these address-space-scoped fences lower to s_waitcnt lgkmcnt(0) only (checked in the .s).
+__device__ __forceinline__ void rt_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}

@@ -2,7 +2,9 @@
 
 What `infer.py:16-22,66-103` and `infer_inpaint.py:83-116` do per text line — render the glyph with PIL, take its bounding
 box, build the position and regional masks, run Canny(50, 100) on the glyph and invert it — restated on numpy so that a host
-without `cv2` can feed `FluxControlNetPipeline.__call__`. This runs once per image on the CPU, outside the timed path.
+without `cv2` can feed `FluxControlNetPipeline.__call__`. This runs once per image, outside the timed path; with `device=` the Canny map and the [0,255] -> [-1,1] preprocessing run on the
+GPU (csrc/hints.hip: rt_canny_u8, rt_preprocess_u8), bit-identical to the numpy restatement below, which stays as their checker
+and as the host path.
 
 `canny_edges` follows the algorithm OpenCV documents for `cv::Canny(image, 50, 100)` with its defaults (3x3 Sobel with
 replicated borders, L1 gradient magnitude, non-maximum suppression over four direction sectors split at tan 22.5° and
@@ -100,13 +102,31 @@ def canny_hint(glyph_rgb: np.ndarray, low_threshold: float = 50, high_threshold:
     return 255 - np.concatenate([e, e, e], axis=2)
 
 
+def canny_hint_device(glyph_rgb: np.ndarray, device, low_threshold: float = 50, high_threshold: float = 100):
+    """`canny()` of infer.py:16-22 followed by VaeImageProcessor.preprocess (PIPE:680), both on the device: the glyph's uint8
+    pixels are uploaded once, rt_canny_u8 writes the inverted 3-channel edge hint, rt_preprocess_u8 turns it into the float32
+    [1,3,H,W] tensor in [-1,1] that `prepare_image` would otherwise build on the host. Bit-identical to
+    preprocess(Image.fromarray(canny_hint(glyph))) (tests/test_hints_gpu.py)."""
+    import torch
+
+    from . import ops
+
+    g = torch.from_numpy(np.ascontiguousarray(glyph_rgb)).to(device)
+    return ops.preprocess_u8(ops.canny_u8(g, low_threshold, high_threshold, invert=True, out_channels=3))
+
+
 def build_text_hints(texts: Sequence[str], positions: Sequence[Tuple[int, int]], colors: Sequence[Tuple[int, int, int]], font,
-                     width: int, height: int, position_margin: int = 0, mask_margin: int = 5):
+                     width: int, height: int, position_margin: int = 0, mask_margin: int = 5, device=None):
     """Per text line: (canny hint RGB, position mask L, regional mask L) and the accumulated glyph image.
 
     `position_margin=0` is infer.py (tight bbox, infer.py:83); `position_margin=5` is infer_inpaint.py:99 (Q11). Returns
     (control_image_list, control_position_list, control_mask_list, control_glyph_all) as PIL images, the arguments
-    `FluxControlNetPipeline.__call__` takes as control_image / control_position / control_mask / control_glyph."""
+    `FluxControlNetPipeline.__call__` takes as control_image / control_position / control_mask / control_glyph.
+
+    `device` (a HIP device): the edge hint and the position hint come back as preprocessed float32 tensors on that device —
+    [1,3,H,W] / [1,1,H,W] in [-1,1], computed by rt_canny_u8 / rt_preprocess_u8 (only the glyph rendering stays PIL; the
+    pipelines take such tensors as they are, PIPE:680,694) — the regional masks and the glyph stay PIL (the pipeline resizes the
+    former on the device itself, the latter goes through its Lanczos-capable preprocess)."""
     images: List[Image.Image] = []
     pos_masks: List[Image.Image] = []
     reg_masks: List[Image.Image] = []
@@ -122,11 +142,19 @@ def build_text_hints(texts: Sequence[str], positions: Sequence[Tuple[int, int]],
             m[max(bbox[1] - margin, 0) : bbox[3] + margin, max(bbox[0] - margin, 0) : bbox[2] + margin] = 255
             return Image.fromarray(m)
 
-        pos_masks.append(box(position_margin))
         reg_masks.append(box(mask_margin))
         g = np.array(glyph)
         glyph_all += g                                  # uint8 wrap-around on overlap, as the script's `+=` does
-        images.append(Image.fromarray(canny_hint(g)))
+        if device is not None:
+            import torch
+
+            from . import ops
+
+            images.append(canny_hint_device(g, device))
+            pos_masks.append(ops.preprocess_u8(torch.from_numpy(np.array(box(position_margin))).to(device)))
+        else:
+            pos_masks.append(box(position_margin))
+            images.append(Image.fromarray(canny_hint(g)))
     return images, pos_masks, reg_masks, Image.fromarray(glyph_all).convert("RGB")
 
 

@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -86,6 +86,7 @@ SIGNATURES.update({
     "rt_groupnorm_silu_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "rt_conv2d_nhwc": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_softmax_rows": [_vp, _vp, _i32, _i32, _f32, _vp],
+    "rt_vae_attention": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_transpose_bf16": [_vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "rt_image_out": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_nchw_to_haloed_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -94,9 +95,15 @@ SIGNATURES.update({
     "rt_resize2d": [_vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "rt_glyph_blend": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
 })
+# hint preparation on the device (csrc/hints.hip)
+SIGNATURES.update({
+    "rt_canny_ws_bytes": [_i32, _i32],
+    "rt_canny_u8": [_vp, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _i32, _vp, _i64, _vp],
+    "rt_preprocess_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+})
 
 # entries that do not return a status code
-RESTYPES = {"rt_groupnorm_ws_bytes": C.c_int64, "rt_attention_fp8_vt_bytes": C.c_int64, "rt_attention_ws_bytes": C.c_int64}
+RESTYPES = {"rt_canny_ws_bytes": C.c_int64, "rt_groupnorm_ws_bytes": C.c_int64, "rt_attention_fp8_vt_bytes": C.c_int64, "rt_attention_ws_bytes": C.c_int64}
 
 _lib = None
 

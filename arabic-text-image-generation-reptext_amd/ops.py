@@ -476,3 +476,35 @@ def glyph_blend(image: torch.Tensor, latents: torch.Tensor, noise: torch.Tensor)
     native.check("rt_glyph_blend", native.load().rt_glyph_blend(_dev(image, "image", F32), _dev(latents, "latents", F32), _dev(noise, "noise", F32),
                                                              out.data_ptr(), B, Cimg, H, W, Cl, OH, OW, _stream()))
     return out
+
+
+def canny_u8(img: torch.Tensor, low: float = 50.0, high: float = 100.0, invert: bool = False, out_channels: int = 1) -> torch.Tensor:
+    """cv2.Canny(img, low, high) of infer.py:16-22 on the device: img uint8 [H,W] or [H,W,C] -> uint8 [H,W,out_channels] edge map
+    {0,255} (255 - edges with ``invert``), bit-identical to hints.canny_edges. One call = four kernels, no host sync."""
+    if img.dtype != torch.uint8 or img.dim() not in (2, 3):
+        raise TypeError("canny_u8: uint8 [H,W] or [H,W,C]")
+    img = img.contiguous()
+    H, W = img.shape[0], img.shape[1]
+    Cc = 1 if img.dim() == 2 else img.shape[2]
+    lib = native.load()
+    ws = torch.empty(int(lib.rt_canny_ws_bytes(H, W)), device=img.device, dtype=torch.uint8)
+    out = torch.empty(H, W, out_channels, device=img.device, dtype=torch.uint8)
+    native.check("rt_canny_u8", lib.rt_canny_u8(_dev(img, "img"), H, W, Cc, float(low), float(high), out.data_ptr(), out_channels, int(invert),
+                                               ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def preprocess_u8(img: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """VaeImageProcessor.preprocess for uint8 images already at the target size: [B,H,W,C] (or [H,W,C] / [H,W]) -> f32 [B,C,H,W]
+    = x/255 (then 2x-1), bit-identical to the host path."""
+    if img.dtype != torch.uint8:
+        raise TypeError("preprocess_u8: uint8 input")
+    if img.dim() == 2:
+        img = img[None, :, :, None]
+    elif img.dim() == 3:
+        img = img[None]
+    img = img.contiguous()
+    B, H, W, Cc = img.shape
+    out = torch.empty(B, Cc, H, W, device=img.device, dtype=F32)
+    native.check("rt_preprocess_u8", native.load().rt_preprocess_u8(_dev(img, "img"), out.data_ptr(), B, H, W, Cc, int(normalize), _stream()))
+    return out

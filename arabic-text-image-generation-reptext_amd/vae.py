@@ -300,8 +300,8 @@ class AutoencoderKL(nn.Module, WeightsIO):
         B, Hp, Wp, C = x.shape
         H, W = Hp - 2, Wp - 2
         HW = H * W
-        if HW % 64:
-            raise ValueError("mid-block attention needs H*W % 64 == 0")
+        if HW % 32 or C not in (128, 256, 512):
+            raise ValueError("mid-block attention needs H*W % 32 == 0 and 128, 256 or 512 channels")
         t = self._gn(a.group_norm, x, False)
         tc = t[:, 1:-1, 1:-1, :].reshape(B, HW, C)               # compact copy of the interior (torch view+copy = plumbing)
         self._pool.put(t)
@@ -310,17 +310,13 @@ class AutoencoderKL(nn.Module, WeightsIO):
                       torch.cat([a.to_q.bias.data, a.to_k.bias.data, a.to_v.bias.data]).contiguous())
         qkv = torch.empty(B, HW, 3 * C, device=x.device, dtype=BF16)
         ops.linear(tc, a._qkv[0], qkv, bias=a._qkv[1])
+        # one head of C channels over HW positions, flash-style: no HW x HW scores (csrc/vae_attention.hip)
         o = torch.empty(B, HW, C, device=x.device, dtype=BF16)
-        scores = torch.empty(HW, HW, device=x.device, dtype=F32)
-        probs = torch.empty(HW, HW, device=x.device, dtype=BF16)
-        vt = torch.empty(C, HW, device=x.device, dtype=BF16)
-        lib = native.load()
+        q, k, v = qkv[..., :C], qkv[..., C : 2 * C], qkv[..., 2 * C :]
+        native.check("rt_vae_attention", native.load().rt_vae_attention(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), qkv.stride(1), qkv.stride(0), o.stride(1), o.stride(0), B, HW, C,
+            1.0 / math.sqrt(C), _stream()))
         for b in range(B):
-            q, k, v = qkv[b, :, :C], qkv[b, :, C : 2 * C], qkv[b, :, 2 * C :]
-            ops.linear(q, k, scores)                               # S = q kᵀ (fp32 out)
-            native.check("rt_softmax_rows", lib.rt_softmax_rows(scores.data_ptr(), probs.data_ptr(), HW, HW, 1.0 / math.sqrt(C), _stream()))
-            native.check("rt_transpose_bf16", lib.rt_transpose_bf16(v.data_ptr(), vt.data_ptr(), HW, C, v.stride(0), HW, _stream()))
-            ops.linear(probs, vt, o[b])                            # O = P v
             # to_out + residual, written row by row into the haloed buffer: batch = image rows
             xin = x[b, 1:-1, 1:-1, :]                              # [H, W, C] strided view of the interior
             ops.linear(o[b].view(H, W, C), a.to_out[0].weight.data, xin, bias=a.to_out[0].bias.data, res=xin)

@@ -238,6 +238,13 @@ int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* r
 /* Row softmax for the VAE mid-block attention (1 head, Dh = 512, computed as GEMM -> softmax -> GEMM):
  * p[r][:] = softmax(scale * s[r][:]), f32 in, bf16 out. cols % 4 == 0. */
 int rt_softmax_rows(const float* s, void* p, int32_t rows, int32_t cols, float scale, void* stream);
+/* Mid-block attention of the AutoencoderKL, flash-style (A.7: Attention(C, 1 head) over the H*W positions of the 1/8-scale grid;
+ * PIPE:1139 decode, PIPE:467,705,711 encode): o = softmax(q k^T * scale) v with ONE head of C channels, C in {128, 256, 512}.
+ * q/k/v: bf16 [B][HW][>=C] views with a common row stride ld and batch stride (elements) — the fused q|k|v projection buffer;
+ * o: bf16 [B][HW][ldo]. HW % 32 == 0. No (HW x HW) buffer exists: the channels are split over the waves of a workgroup, which
+ * exchange partial scores through LDS (csrc/vae_attention.hip). Replaces GEMM -> rt_softmax_rows -> rt_transpose_bf16 -> GEMM. */
+int rt_vae_attention(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
+                     int32_t B, int32_t HW, int32_t C, float scale, void* stream);
 /* out[c][r] = in[r][c], bf16 (V^T for the P·V GEMM). */
 int rt_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out, void* stream);
 /* Decoder tail: haloed NHWC f32 [B][H+2][W+2][Cp] -> NCHW f32 [B][C][H][W] (nchw, optional) and/or uint8 HWC
@@ -263,6 +270,24 @@ int rt_resize2d(const void* in, int32_t in_u8, float in_scale, float* out, int32
  * to the latent grid, is > 0; noise elsewhere. image f32 [B][Cimg][H][W]; latents, noise, out f32 [B][Cl][OH][OW]. */
 int rt_glyph_blend(const float* image, const float* latents, const float* noise, float* out, int32_t B, int32_t Cimg, int32_t H, int32_t W,
                    int32_t Cl, int32_t OH, int32_t OW, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Caller-side hint preparation on the device (csrc/hints.hip).
+ * ---------------------------------------------------------------------------------------- */
+/* cv2.Canny(image, low, high) of infer.py:16-22 (called at infer.py:98-100 on the rendered glyph) as cv::Canny documents it —
+ * 3x3 Sobel with replicated borders taken per channel (the channel with the largest |dx|+|dy| supplies the gradient, first
+ * channel on ties; no gray conversion), L1 magnitude, 4-sector non-maximum suppression with cv::Canny's tie rules, double
+ * threshold, 8-connected hysteresis — bit-identical to reptext_amd/hints.py::canny_edges (parity with OpenCV itself is unpinned).
+ * img: uint8 [H][W][C] (C = 1..4, interleaved); out: uint8 [H][W][out_channels], every channel = edge map {0,255}, or
+ * 255 - edges when `invert` (infer.py:20-22: the hint is the inverted map repeated over 3 channels).
+ * ws: rt_canny_ws_bytes(H, W) bytes of scratch, 256-byte aligned; need not be zeroed. Four kernels on `stream`, no host
+ * round trip (hysteresis = one workgroup's breadth-first search over index frontiers in ws). */
+int64_t rt_canny_ws_bytes(int32_t H, int32_t W);
+int rt_canny_u8(const uint8_t* img, int32_t H, int32_t W, int32_t C, float low, float high, uint8_t* out, int32_t out_channels,
+                int32_t invert, void* ws, int64_t ws_bytes, void* stream);
+/* VaeImageProcessor.preprocess (PIPE:680,694,970) for uint8 images that already have the target size: img [B][H][W][C] ->
+ * out f32 [B][C][H][W] = x / 255, then 2x - 1 when `normalize` (the same fp32 roundings numpy/torch take: bit-identical). */
+int rt_preprocess_u8(const uint8_t* img, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t normalize, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,114 @@
+"""AutoencoderKL at the REAL FLUX VAE config — block_out_channels (128, 256, 512, 512) — and its flash mid-block attention.
+PIPE:1136-1140 (decode), PIPE:467,705,711 (encode); SURVEY.md Appendix A.7. VERDICT r2 items: the real config was only ever
+run by bench.py; the mid-block attention materialised its (H·W)² scores."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_oracle as orc  # noqa: E402
+from oracle import vae_oracle as vorc  # noqa: E402
+from test_models_gpu import assert_at_dtype_floor  # noqa: E402
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def real_vae(gpu):
+    from reptext_amd.vae import AutoencoderKL
+
+    cfg = dict(vorc.FLUX_VAE_CFG)
+    assert tuple(cfg["block_out_channels"]) == (128, 256, 512, 512)
+    p = vorc.init_vae_params(cfg, seed=5)
+    vae = AutoencoderKL(**cfg, device=gpu, dtype=torch.bfloat16)
+    vae.load_state_dict(p, strict=True)
+    return cfg, p, vae
+
+
+@pytest.mark.parametrize("C,HW,B", [(512, 1024, 1), (512, 4096, 2), (256, 1024, 1), (128, 96, 3)])
+def test_vae_attention_kernel_vs_fp32(gpu, C, HW, B):
+    """rt_vae_attention (one head of C channels, channels split over the waves of a workgroup) against fp32 softmax attention on
+    the same bf16 inputs; q/k/v are column slices of one fused buffer, as the VAE hands them over. Includes a spiked key (the
+    deferred-rescale branch must fire on a row whose maximum jumps late) and bitwise repeatability."""
+    from reptext_amd import native
+
+    g = torch.Generator().manual_seed(C + HW)
+    qkv = (torch.randn(B, HW, 3 * C, generator=g) * 1.5).to(torch.bfloat16)
+    qkv[:, HW // 2 + 5, C : 2 * C] = qkv[:, 7, :C] * 3.0          # key HW/2+5 aligned with query 7: its score towers over the rest
+    ref = torch.softmax((qkv[..., :C].float() @ qkv[..., C : 2 * C].float().transpose(1, 2)) / math.sqrt(C), dim=-1) @ qkv[..., 2 * C :].float()
+    d = qkv.to(gpu)
+    o = torch.empty(B, HW, C, device=gpu, dtype=torch.bfloat16)
+    lib, st = native.load(), torch.cuda.current_stream().cuda_stream
+    call = lambda out: native.check("rt_vae_attention", lib.rt_vae_attention(
+        d.data_ptr(), d[..., C:].data_ptr(), d[..., 2 * C :].data_ptr(), out.data_ptr(), d.stride(1), d.stride(0), out.stride(1), out.stride(0),
+        B, HW, C, 1.0 / math.sqrt(C), st))
+    call(o)
+    err = rel_l2(o.float().cpu(), ref)
+    row7 = rel_l2(o[:, 7].float().cpu(), ref[:, 7])
+    print(f"vae attention C={C} HW={HW} B={B}: rel-L2 {err:.3e} (spiked row {row7:.3e})")
+    assert err < 6e-3 and row7 < 1e-2                               # bf16 numerators and output: the MMDiT attention's bound
+    o2 = torch.empty_like(o)
+    call(o2)
+    assert torch.equal(o, o2)
+    with pytest.raises(native.NativeCallError):                    # shapes the kernel does not take are rejected, not mangled
+        native.check("rt_vae_attention", lib.rt_vae_attention(d.data_ptr(), d.data_ptr(), d.data_ptr(), o.data_ptr(), d.stride(1), d.stride(0),
+                                                               o.stride(1), o.stride(0), B, HW - 8, C, 1.0, st))
+
+
+def test_real_config_decode_and_encode_vs_oracle(real_vae, gpu):
+    """Decode of a 32x32 latent to 256x256 and encode of a 256x256 image at the real widths (512-channel mid block: the
+    4-wave channel-split attention kernel; 512 -> 256 -> 128 shortcut convolutions) against vae_oracle, at the bf16-storage floor."""
+    cfg, p, vae = real_vae
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(1, 16, 32, 32, generator=g).to(torch.bfloat16).float()
+    ref = vorc.decode(p, cfg, z)
+    out = vae.decode(z.to(gpu, torch.bfloat16), return_dict=False)[0].float().cpu()
+    with orc.stored_as(torch.bfloat16):
+        ref16 = vorc.decode(p, cfg, z)
+    err, err16, floor = rel_l2(out, ref), rel_l2(out, ref16), rel_l2(ref16, ref)
+    print(f"REAL-config vae decode 256x256: rel-L2 {err:.3e} vs fp32 oracle, {err16:.3e} vs bf16-storage oracle (floor {floor:.3e})")
+    assert out.shape == (1, 3, 256, 256) and err < 3e-2
+    assert_at_dtype_floor(err, err16, floor)
+    x = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    mean, logvar = vorc.encode_moments(p, cfg, x)
+    dist = vae.encode(x.to(gpu, torch.bfloat16)).latent_dist
+    with orc.stored_as(torch.bfloat16):
+        mean16, logvar16 = vorc.encode_moments(p, cfg, x)
+    e1, e2 = rel_l2(dist.mean.float().cpu(), mean), rel_l2(dist.logvar.float().cpu(), logvar)
+    print(f"REAL-config vae encode 256x256: rel-L2 mean {e1:.3e} logvar {e2:.3e} (floors {rel_l2(mean16, mean):.3e} {rel_l2(logvar16, logvar):.3e})")
+    assert_at_dtype_floor(e1, rel_l2(dist.mean.float().cpu(), mean16), rel_l2(mean16, mean))
+    assert_at_dtype_floor(e2, rel_l2(dist.logvar.float().cpu(), logvar16), rel_l2(logvar16, logvar))
+
+
+def test_decode_1024_properties_and_no_score_matrix(real_vae, gpu):
+    """The BASELINE-size decode (128x128 latent -> 1024x1024 uint8; PIPE:1136-1140): finite, bitwise repeatable, a non-degenerate
+    histogram. And the mid-block attention at the 1536^2 grid (192x192 = 36 864 positions) must not allocate anything near the
+    5.4 GB its score matrix would take."""
+    cfg, p, vae = real_vae
+    g = torch.Generator().manual_seed(22)
+    packed = torch.randn(1, 64 * 64, 64, generator=g).to(gpu, torch.bfloat16)
+    u8 = vae.decode_packed(packed, 128, 128, output_u8=True)
+    assert u8.shape == (1, 1024, 1024, 3) and u8.dtype == torch.uint8
+    assert torch.equal(u8, vae.decode_packed(packed, 128, 128, output_u8=True))
+    f32 = vae.decode_packed(packed, 128, 128)
+    assert bool(torch.isfinite(f32).all())
+    hist = torch.bincount(u8.flatten().to(torch.int64), minlength=256).float()
+    assert int((hist > 0).sum()) > 64 and float((hist[0] + hist[255]) / hist.sum()) < 0.9 and float(u8.float().std()) > 5
+    # mid-block attention alone at 192 x 192 positions
+    a = vae.decoder.mid_block.attentions[0]
+    x = torch.zeros(1, 194, 194, 512, device=gpu, dtype=torch.bfloat16)
+    x[:, 1:-1, 1:-1] = torch.randn(1, 192, 192, 512, generator=g).to(gpu, torch.bfloat16)
+    vae._ready()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    y = vae._mid_attn(a, x)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    print(f"mid-block attention at 36864 positions: peak extra memory {peak / 2**20:.0f} MiB")
+    assert peak < 600 * 2**20 and bool(torch.isfinite(y.float()).all())
