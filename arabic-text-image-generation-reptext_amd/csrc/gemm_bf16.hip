@@ -23,40 +23,70 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BK = 64;
 constexpr int THREADS = 512;
-constexpr int TILE_BYTES = BM * BK * 2;           // 32 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;         // A + W
-constexpr int LDS_BYTES = 2 * BUF_BYTES;          // double buffered: 128 KiB
+
+// Tile geometry. 8 waves as 2(M) x 4(N); a wave's output is (NI0+NI1) x (NJ0+NJ1) fragments of 16x16, consumed per K-tile in the
+// four quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0) of its "halves" (a0 = first NI0 row fragments, b0 = first NJ0 column fragments).
+//   Geo<4,4,2,2>  256x256  the general tile (128 accumulator registers per lane, 128 KiB of LDS)
+//   Geo<5,4,2,1>  288x192  M = 4608 x N = 3072 is EXACTLY 256 of these (16 x 16): the single blocks' out-projection fills all 256
+//                          CUs in one round instead of 216 tiles of 256x256 on 256 CUs (84 %); 108 accumulator registers, 136 KiB
+//   Geo<4,4,2,1>  256x192  } narrower tiles for the TAIL of a multi-round launch (gemm_mix_kernel): the columns that would form a
+//   Geo<4,4,1,1>  256x128  } partly filled last round of 256x256 tiles are cut into 3/4- or 1/2-width tiles instead
+// The K order of every output element is the same in all of them, so results are bit-identical whatever tile computed them.
+template <int NI0_, int NI1_, int NJ0_, int NJ1_>
+struct Geo {
+  static constexpr int NI0 = NI0_, NI1 = NI1_, NJ0 = NJ0_, NJ1 = NJ1_;
+  static constexpr int NI = NI0 + NI1, NJ = NJ0 + NJ1;
+  static constexpr int NIH = NI0 > NI1 ? NI0 : NI1, NJH = NJ0 > NJ1 ? NJ0 : NJ1;
+  static constexpr int WMR = 16 * NI, WNC = 16 * NJ;          // rows / columns per wave
+  static constexpr int BM = 2 * WMR, BN = 4 * WNC;
+  static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+  // LDS-DMA pieces (8 rows x 128 B = 1 KiB, one wave-instruction) per wave and operand part; an a-half of 4*NIh pieces that does
+  // not divide by 8 waves is padded with dummy pieces (landing in a scratch region) so that every wave issues the same count
+  static constexpr int PA0 = (4 * NI0 + 7) / 8, PA1 = (4 * NI1 + 7) / 8, PB0 = NJ0, PB1 = NJ1;
+  static constexpr bool DUMMY = (4 * NI0) % 8 != 0 || (4 * NI1) % 8 != 0;
+  static constexpr int DUMMY_BYTES = DUMMY ? 8 * 1024 : 0;
+  static constexpr int BUF_BYTES = A_BYTES + W_BYTES + DUMMY_BYTES;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;             // double buffered
+};
+using Geo256 = Geo<4, 4, 2, 2>;
+using Geo288 = Geo<5, 4, 2, 1>;
+using Geo192 = Geo<4, 4, 2, 1>;
+using Geo128 = Geo<4, 4, 1, 1>;
+constexpr int LDS_MAX = Geo288::LDS_BYTES > Geo256::LDS_BYTES ? Geo288::LDS_BYTES : Geo256::LDS_BYTES;
 
 struct GroupDev {
   rt_gemm_group g;
   int tiles_m, tiles_n, tile_begin;
   int wide_store;      // bf16 output rows are 16-byte addressable in 8-column steps (C 16-B aligned, ldc/strideC/N % 8 == 0)
+  // gemm_mix_kernel only: columns [0, n_split) are cut into 256-wide tiles, [n_split, N) into narrow ones
+  int n_split, tiles_n_narrow, narrow_begin;
 };
 struct Launch {
   GroupDev grp[RT_GEMM_MAX_GROUPS];
   int ngroups;
+  int wide_total, narrow_total;      // gemm_mix_kernel: tiles of each kind over all groups
 };
 
-// Epilogue for one wave: 8x4 accumulator fragments -> C. Lane owns rows mrow + 16i (i<8) and, per fragment column j,
-// the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the 4 fragment columns;
+// Epilogue for one wave: NI x NJ accumulator fragments -> C. Lane owns rows mrow + 16i and, per fragment column j,
+// the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the fragment columns;
 // per-row terms (residual, add2) are fetched one row ahead of the row being finished, so no store waits on a load.
-template <bool OUT_F32, bool FP8 = false>
-__device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[8][4], bool wide = false) {
+template <bool OUT_F32, bool FP8, int NI, int NJ>
+__device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[NI][NJ], bool wide = false) {
   const int rpb = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
-  bool nok[4];
-  f32x4 bias4[4], gate4[4];
-  f32x4 wsc4[4];                                        // fp8 only: de-quantisation scale of the 4 output channels
+  bool nok[NJ];
+  f32x4 bias4[NJ], gate4[NJ];
+  f32x4 wsc4[NJ];                                       // fp8 only: de-quantisation scale of the 4 output channels
   if constexpr (FP8) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int n = ncol + 16 * j;
       wsc4[j] = g.w_scale ? *reinterpret_cast<const f32x4*>(g.w_scale + (n < g.N ? n : 0)) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = ncol + 16 * j;
     nok[j] = n < g.N;
     const int nc = nok[j] ? n : 0;                    // clamp: masked columns read column 0, never stored
@@ -72,16 +102,16 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
   const bool gate_per_row = g.gate && ((rpb < g.M) || FP8);
   if (g.gate && !gate_per_row) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
       gate4[j] = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)bidx * g.gate_ld + (nok[j] ? ncol + 16 * j : 0));
   }
   typedef typename std::conditional<OUT_F32, f32x4, u32x2>::type res_t;
-  res_t rnext[4];
-  u32x2 anext[4];
+  res_t rnext[NJ];
+  u32x2 anext[NJ];
   auto fetch_row = [&](int i) {
     const int m = min(mrow + 16 * i, g.M - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int nc = nok[j] ? ncol + 16 * j : 0;
       if (g.res) {
         const int64_t roff = (int64_t)bidx * g.strideR + (int64_t)m * g.ldr + nc;
@@ -93,18 +123,18 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
   };
   if (g.res || g.add2) fetch_row(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int m = mrow + 16 * i;
-    res_t rcur[4];
-    u32x2 acur[4];
+    res_t rcur[NJ];
+    u32x2 acur[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { rcur[j] = rnext[j]; acur[j] = anext[j]; }
-    if ((g.res || g.add2) && i + 1 < 8) fetch_row(i + 1);
+    for (int j = 0; j < NJ; ++j) { rcur[j] = rnext[j]; acur[j] = anext[j]; }
+    if ((g.res || g.add2) && i + 1 < NI) fetch_row(i + 1);
     const int mc = min(m, g.M - 1);
     const float rs = g.rowscale ? g.rowscale[(int64_t)bidx * g.stride_rowscale + mc % rpb] * g.alpha : g.alpha;
-    u32x2 packed[4];                                   // bf16 results of the 4 fragment columns (wide-store path)
+    u32x2 packed[NJ];                                  // bf16 results of the fragment columns (wide-store path)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int n = ncol + 16 * j;
       f32x4 v;
       if constexpr (FP8) v = acc[i][j] * (wsc4[j] * (g.a_scale ? g.a_scale[(int64_t)bidx * g.M + mc] : 1.f)) + bias4[j];
@@ -135,7 +165,7 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
           u32x2 o;
           o[0] = pack_bf16x2(v[0], v[1]);
           o[1] = pack_bf16x2(v[2], v[3]);
-          if (!wide) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
+          if (!wide || (NJ % 2 == 1 && j == NJ - 1)) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + coff) = o;
         }
       }
       if constexpr (!OUT_F32) {
@@ -144,15 +174,15 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
       }
     }
     if constexpr (!OUT_F32) {
-      // Wide store: the four 16-lane groups c of a wave hold columns 4c..4c+3 of each 16-column fragment — 8 bytes per lane,
-      // 32 stores per tile. v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another;
-      // applied to the registers of fragments (j, j+1) it leaves every lane with 8 CONSECUTIVE columns (its own 4 plus its
-      // neighbour group's): groups 0/2 take fragment j, groups 1/3 fragment j+1. Same bytes, same addresses, half the store
-      // instructions (the store tail of a tile is issue-bound).
+      // Wide store: the four 16-lane groups c of a wave hold columns 4c..4c+3 of each 16-column fragment — 8 bytes per lane.
+      // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another; applied to the registers
+      // of fragments (j, j+1) it leaves every lane with 8 CONSECUTIVE columns (its own 4 plus its neighbour group's): groups
+      // 0/2 take fragment j, groups 1/3 fragment j+1. Same bytes, same addresses, half the store instructions (the store tail of
+      // a tile is issue-bound). An odd last fragment column is stored narrow (above).
       if (wide) {
         const int c = (ncol >> 2) & 3;                // this lane's 16-lane group
 #pragma unroll
-        for (int jp = 0; jp < 4; jp += 2) {
+        for (int jp = 0; jp + 1 < NJ; jp += 2) {
           const auto x = __builtin_amdgcn_permlane16_swap(packed[jp][0], packed[jp + 1][0], false, false);
           const auto y = __builtin_amdgcn_permlane16_swap(packed[jp][1], packed[jp + 1][1], false, false);
           const int n8 = (ncol - 4 * c) + 16 * (jp + (c & 1)) + 8 * (c >> 1);       // first of this lane's 8 columns
@@ -167,16 +197,17 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gemm_pp_kernel: the ping-pong schedule.
-//   * a K-tile is consumed in 4 phases of 16 MFMAs, one quadrant of the wave's 128x64 output each, in the order
-//     (a0,b0) (a0,b1) (a1,b1) (a1,b0) so only 12+4+8+0 fragment reads are needed per K-tile;
+// gemm_tile: one output tile, the ping-pong schedule.
+//   * a K-tile is consumed in 4 phases, one quadrant of the wave's output each, in the order (a0,b0) (a0,b1) (a1,b1) (a1,b0)
+//     so only (NI0+NJ0) + NJ1 + NI1 + 0 fragment reads (x2 k-steps) are needed per K-tile;
 //   * waves 4-7 run one barrier behind waves 0-3, so of the two waves that share a SIMD one is in its MFMA cluster
 //     while the other reads fragments / issues LDS-DMA: the matrix pipe always has a wave feeding it;
-//   * the operand parts a0,b0,b1,a1 of tile t+1 are issued (2 LDS-DMA per wave) in phases 1..4 of tile t and
-//     consumed in the same order one tile later; they stay in flight ACROSS the barriers behind a counted
-//     s_waitcnt vmcnt(4) (never 0 in steady state). Each wait sits before the barrier that precedes the MFMA
-//     cluster, i.e. one barrier earlier than the first read of that data by EITHER wave group (the staggered group
-//     reads one barrier later), which is what orders LDS-DMA writes for other waves' ds_reads.
+//   * the operand parts a0,b0,b1,a1 of tile t+1 are issued (PA0, PB0, PB1, PA1 LDS-DMA pieces per wave) in phases 1..4 of tile t
+//     and consumed in the same order one tile later; they stay in flight ACROSS the barriers behind counted s_waitcnt vmcnt
+//     (never 0 in steady state). Each wait sits before the barrier that precedes the MFMA cluster, i.e. one barrier earlier
+//     than the first read of that data by EITHER wave group (the staggered group reads one barrier later), which is what orders
+//     LDS-DMA writes for other waves' ds_reads. The counts: a wait that must cover part X leaves exactly the pieces issued after
+//     X outstanding (vmcnt counts in issue order).
 // ---------------------------------------------------------------------------------------------------
 #define RT_BAR()                              \
   do {                                        \
@@ -184,7 +215,19 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     __builtin_amdgcn_s_barrier();             \
     __builtin_amdgcn_sched_barrier(0);        \
   } while (0)
-#define RT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void rt_vmcnt() {
+  static_assert(N >= 0 && N <= 8, "vmcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -195,167 +238,162 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 //              The MFMA's lane group j (lane>>4) is given the two 16-byte chunks j and j+4 of the row as its 32 k-values —
 //              the chunks the bf16 form reads for its k-steps 0 and 1 — for both operands alike, so the contraction still
 //              covers every k exactly once and the reads keep their conflict-free pattern.
-template <bool FP8>
-__global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
+template <bool FP8, class G_>
+__device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int m0, int n0, bool wide_store, char* smem) {
+  using T = G_;
   constexpr int ESZ = FP8 ? 1 : 2;                   // bytes per operand element
   constexpr int BKE = 128 / ESZ;                     // elements per K-tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
-  LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  (void)L;
-  // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so
-  // blocks b and b+8 share an L2. Remap so each XCD owns a CONTIGUOUS run of the tile order (bijective for any grid
-  // size), then walk each problem in panels of 8 tile-columns, row by row: the 32 tiles an XCD runs at a time form
-  // a ~4x8 patch that shares 4 A row-panels and 8 W row-panels in that XCD's L2 instead of ~9 and ~14.
-  const int nwg = (int)gridDim.x;
-  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  int gi = 0;
-#pragma unroll
-  for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
-    if (i < Lp->ngroups && lin >= Lp->grp[i].tile_begin) gi = i;
-#if defined(__HIP_DEVICE_COMPILE__)
-  const GroupDev G = Lp->grp[gi];
-#else
-  const GroupDev G = L.grp[0];
-#endif
-  const rt_gemm_group& g = G.g;
-  int t = lin - G.tile_begin;
-  const int tiles_per_batch = G.tiles_m * G.tiles_n;
-  const int bidx = t / tiles_per_batch;
-  t -= bidx * tiles_per_batch;
-  constexpr int PANEL = 8;
-  const int panel = t / (PANEL * G.tiles_m);
-  const int pw = min(PANEL, G.tiles_n - panel * PANEL);          // width of this (possibly last, narrower) panel
-  const int tp = t - panel * PANEL * G.tiles_m;
-  const int tm = tp / pw;
-  const int tn = panel * PANEL + (tp - tm * pw);
-  const int m0 = tm * BM, n0 = tn * BN;
-
+  constexpr int NPC = T::PA0 + T::PB0 + T::PB1 + T::PA1;          // pieces per wave and K-tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  // ---- staging: part 0 = a0, 1 = b0, 2 = b1, 3 = a1; each wave stages 16 rows (2 pieces of 8) of every part.
-  //      a-part rows r' in [0,128): tile row = r' + 64*ah + (r' >= 64 ? 64 : 0)      (rows of both wave rows' half ah)
-  //      b-part rows r' in [0,128): tile row = (r'/32)*64 + 32*bh + r'%32            (rows of all four wave cols' half bh)
+  // ---- staging. LDS image: A tile rows in tile order (wave row wm at wm*WMR, its half 1 at +16*NI0), W tile rows likewise
+  //      (wave column wn at wn*WNC, half 1 at +16*NJ0), 128 B per row, 16-byte chunk c of row r at c ^ ((r>>1)&7).
+  //      Part a-half h = rows of BOTH wave rows' half h (4*NIh pieces of 8 rows), part b-half h = rows of all four wave columns'
+  //      half h (8*NJh pieces); wave w issues pieces w, w+8, ... of every part.
   const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)bidx * g.strideA * ESZ;
   const char* Wb = reinterpret_cast<const char*>(g.W);
-  uint32_t src[4][2];     // byte offsets from Ab / Wb (both tensors are < 2^32 bytes; checked on the host)
-  int lds_off[4][2];
-#pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    const bool is_a = (part == 0 || part == 3);
-    const int half = (part == 2 || part == 3) ? 1 : 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      int rowbase;   // wave-uniform first row of this 8-row piece inside its operand tile
-      if (is_a) rowbase = wave * 16 + q * 8 + 64 * half + (wave >= 4 ? 64 : 0);
-      else rowbase = (wave >> 1) * 64 + 32 * half + (wave & 1) * 16 + q * 8;
+  uint32_t src[NPC];      // byte offsets from Ab / Wb (both tensors are < 2^32 bytes; checked on the host)
+  int lds_off[NPC];
+  {
+    int k = 0;
+    auto a_piece = [&](int half, int q) {
+      constexpr int dummy_base = T::A_BYTES + T::W_BYTES;
+      const int nih = half ? T::NI1 : T::NI0;
+      const int p = wave + 8 * q;
+      const bool real = p < 4 * nih;
+      const int pp = real ? p : p - 8 * ((p - 4 * nih) / 8 + 1);          // a dummy piece re-reads one of this wave's earlier pieces
+      const int wmp = pp / (2 * nih), within = pp - wmp * 2 * nih;
+      const int rowbase = wmp * T::WMR + (half ? 16 * T::NI0 : 0) + within * 8;
       const int row = rowbase + (lane >> 3);
       const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      if (is_a) {
-        const int am = min(m0 + row, g.M - 1);
-        src[part][q] = (uint32_t)(((int64_t)am * g.lda) * ESZ + lc * 16);
-        lds_off[part][q] = rowbase * 128;
-      } else {
-        const int wr = min(n0 + row, g.N - 1);
-        src[part][q] = (uint32_t)(((int64_t)wr * g.ldw) * ESZ + lc * 16);
-        lds_off[part][q] = TILE_BYTES + rowbase * 128;
-      }
-    }
+      const int am = min(m0 + row, g.M - 1);
+      src[k] = (uint32_t)(((int64_t)am * g.lda) * ESZ + lc * 16);
+      lds_off[k] = real ? rowbase * 128 : dummy_base + wave * 1024;
+      ++k;
+    };
+    auto b_piece = [&](int half, int q) {
+      const int njh = half ? T::NJ1 : T::NJ0;
+      const int p = wave + 8 * q;                                           // < 8*njh always
+      const int wnp = p / (2 * njh), within = p - wnp * 2 * njh;
+      const int rowbase = wnp * T::WNC + (half ? 16 * T::NJ0 : 0) + within * 8;
+      const int row = rowbase + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      const int wr = min(n0 + row, g.N - 1);
+      src[k] = (uint32_t)(((int64_t)wr * g.ldw) * ESZ + lc * 16);
+      lds_off[k] = T::A_BYTES + rowbase * 128;
+      ++k;
+    };
+#pragma unroll
+    for (int q = 0; q < T::PA0; ++q) a_piece(0, q);
+#pragma unroll
+    for (int q = 0; q < T::PB0; ++q) b_piece(0, q);
+#pragma unroll
+    for (int q = 0; q < T::PB1; ++q) b_piece(1, q);
+#pragma unroll
+    for (int q = 0; q < T::PA1; ++q) a_piece(1, q);
   }
   // LDS-DMA by buffer_load ... lds: 4-SGPR descriptor per operand + the lane's invariant 32-bit byte offset + the K offset in an
   // SGPR — no per-K-tile vector address arithmetic and half the address registers of the global_load form.
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab), 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, -1, 0x00020000);
-  auto issue = [&](int part, int buf, int koff) {                        // koff in BYTES along the row
+  // part 0 = a0, 1 = b0, 2 = b1, 3 = a1 (issue order inside a K-tile)
+  auto issue = [&](auto part_c, int buf, int koff) {                     // koff in BYTES along the row
+    constexpr int part = decltype(part_c)::value;
+    constexpr int first = part == 0 ? 0 : part == 1 ? T::PA0 : part == 2 ? T::PA0 + T::PB0 : T::PA0 + T::PB0 + T::PB1;
+    constexpr int cnt = part == 0 ? T::PA0 : part == 1 ? T::PB0 : part == 2 ? T::PB1 : T::PA1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * BUF_BYTES + lds_off[part][q]), 16,
-                                               (int)src[part][q], koff, 0, 0);
+    for (int q = 0; q < cnt; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
+                                               (int)src[first + q], koff, 0, 0);
   };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
 
   const int l15 = lane & 15;
   const int sw = (lane >> 1) & 7;
   const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
-  const int a_base = wm * 128 * 128;
-  const int w_base = TILE_BYTES + wn * 64 * 128;
+  const int a_base = wm * T::WMR * 128;
+  const int w_base = T::A_BYTES + wn * T::WNC * 128;
 
-  f32x4 acc[8][4];
+  f32x4 acc[T::NI][T::NJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < T::NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2];        // current a-half: [frag][kk]
-  bf16x8 wf[2][2][2];     // both b-halves: [half][frag][kk]
+    for (int j = 0; j < T::NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[T::NIH][2];        // current a-half: [frag][kk]
+  bf16x8 wf[2][T::NJH][2];     // both b-halves: [half][frag][kk]
 
+#define RT_NIH(ah) ((ah) ? T::NI1 : T::NI0)
+#define RT_NJH(bh) ((bh) ? T::NJ1 : T::NJ0)
 #define RT_READ_A(ah)                                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
-    af[i][0] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*4 + i) * 2048 + rd0);                          \
-    af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*4 + i) * 2048 + rd1);                          \
+  _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i) {                                                        \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd0);                     \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd1);                     \
   }
 #define RT_READ_B(bh)                                                                                             \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
-    wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd0);                      \
-    wf[bh][j][1] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*2 + j) * 2048 + rd1);                      \
+  _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j) {                                                        \
+    wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*T::NJ0 + j) * 2048 + rd0);                 \
+    wf[bh][j][1] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*T::NJ0 + j) * 2048 + rd1);                 \
   }
 #define RT_CAT8(lo, hi) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7)
 #define RT_MFMA(ah, bh)                                                                                           \
   do {                                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     if constexpr (FP8) {                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-          acc[(ah)*4 + i][(bh)*2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                         \
-              RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*4 + i][(bh)*2 + j],      \
+      _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j)                                                    \
+          acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
+              RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j], \
               0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* 2^0 */, 0, 0x7F7F7F7F);                            \
     } else {                                                                                                      \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
-            acc[(ah)*4 + i][(bh)*2 + j] =                                                                         \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*4 + i][(bh)*2 + j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                    \
+          _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j)                                                  \
+            acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[bh][j][kk], af[i][kk], acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j], 0, 0, 0); \
     }                                                                                                             \
     __builtin_amdgcn_s_setprio(0);                                                                                \
   } while (0)
 
   const int nk = g.K / BKE;
-  issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0); issue(3, 0, 0);
-  RT_VMCNT(4);
+  issue(P0{}, 0, 0); issue(P1{}, 0, 0); issue(P2{}, 0, 0); issue(P3{}, 0, 0);
+  rt_vmcnt<T::PB1 + T::PA1>();                 // a0, b0 of tile 0 landed (younger: b1, a1)
   RT_BAR();
   if (wm == 1) RT_BAR();                       // stagger waves 4-7 by one barrier
 
   for (int kt = 0; kt + 1 < nk; ++kt) {
-    const char* tb = smem + (kt & 1) * BUF_BYTES;
+    const char* tb = smem + (kt & 1) * T::BUF_BYTES;
     const int nb = (kt & 1) ^ 1;
     const int koff = (kt + 1) * 128;           // bytes
     // ---- phase 1: (a0,b0)
     RT_READ_A(0); RT_READ_B(0);
-    issue(0, nb, koff);
-    RT_VMCNT(4);                               // b1(kt) landed (younger: a1(kt), a0(kt+1))
+    issue(P0{}, nb, koff);
+    rt_vmcnt<T::PA1 + T::PA0>();               // b1(kt) landed (younger: a1(kt), a0(kt+1))
     RT_BAR(); RT_MFMA(0, 0); RT_BAR();
     // ---- phase 2: (a0,b1)
     RT_READ_B(1);
-    issue(1, nb, koff);
-    RT_VMCNT(4);                               // a1(kt) landed (younger: a0(kt+1), b0(kt+1))
+    issue(P1{}, nb, koff);
+    rt_vmcnt<T::PA0 + T::PB0>();               // a1(kt) landed (younger: a0(kt+1), b0(kt+1))
     RT_BAR(); RT_MFMA(0, 1); RT_BAR();
     // ---- phase 3: (a1,b1)
     RT_READ_A(1);
-    issue(2, nb, koff);
+    issue(P2{}, nb, koff);
     RT_BAR(); RT_MFMA(1, 1); RT_BAR();
     // ---- phase 4: (a1,b0)  (b0 still in registers)
-    issue(3, nb, koff);
-    RT_VMCNT(4);                               // a0(kt+1), b0(kt+1) landed (younger: b1(kt+1), a1(kt+1))
+    issue(P3{}, nb, koff);
+    rt_vmcnt<T::PB1 + T::PA1>();               // a0(kt+1), b0(kt+1) landed (younger: b1(kt+1), a1(kt+1))
     RT_BAR(); RT_MFMA(1, 0); RT_BAR();
   }
   {                                            // last K-tile: nothing left to issue, drain
-    const char* tb = smem + ((nk - 1) & 1) * BUF_BYTES;
+    const char* tb = smem + ((nk - 1) & 1) * T::BUF_BYTES;
     RT_READ_A(0); RT_READ_B(0);
-    RT_VMCNT(0);
+    rt_vmcnt<0>();
     RT_BAR(); RT_MFMA(0, 0); RT_BAR();
     RT_READ_B(1);
     RT_BAR(); RT_MFMA(0, 1); RT_BAR();
@@ -368,11 +406,121 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
 #undef RT_READ_B
 #undef RT_MFMA
 #undef RT_CAT8
+#undef RT_NIH
+#undef RT_NJH
 
-  const int mrow = m0 + wm * 128 + l15;
-  const int ncol = n0 + wn * 64 + 4 * (lane >> 4);
-  if (g.out_f32) epilogue_tile<true, FP8>(g, bidx, mrow, ncol, acc);
-  else epilogue_tile<false, FP8>(g, bidx, mrow, ncol, acc, G.wide_store != 0);
+  const int mrow = m0 + wm * T::WMR + l15;
+  const int ncol = n0 + wn * T::WNC + 4 * (lane >> 4);
+  if (g.out_f32) epilogue_tile<true, FP8, T::NI, T::NJ>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false, FP8, T::NI, T::NJ>(g, bidx, mrow, ncol, acc, wide_store);
+}
+
+// XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8
+// share an L2. `xcd_run` gives XCD group x a CONTIGUOUS run of an n-item order (bijective for any n): item index of slot s.
+__device__ __forceinline__ int xcd_run_start(int n, int xcd) {
+  const int q8 = n >> 3, r8 = n & 7;
+  return xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+}
+__device__ __forceinline__ int xcd_run_count(int n, int xcd) { return (n >> 3) + (xcd < (n & 7) ? 1 : 0); }
+
+// Walk one problem in panels of 8 tile-columns, row by row: the 32 tiles an XCD runs at a time form a ~4x8 patch that shares
+// 4 A row-panels and 8 W row-panels in that XCD's L2 instead of ~9 and ~14.
+__device__ __forceinline__ void panel_walk(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int PANEL = 8;
+  const int panel = t / (PANEL * tiles_m);
+  const int pw = min(PANEL, tiles_n - panel * PANEL);          // width of this (possibly last, narrower) panel
+  const int tp = t - panel * PANEL * tiles_m;
+  tm = tp / pw;
+  tn = panel * PANEL + (tp - tm * pw);
+}
+
+typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
+
+// One geometry for the whole launch (G_ = Geo256: every ordinary launch; Geo288: M x N a whole number of 288x192 tiles).
+template <bool FP8, class G_>
+__global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)L;
+  const int nwg = (int)gridDim.x;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int lin = xcd_run_start(nwg, xcd) + slot;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
+    if (i < Lp->ngroups && lin >= Lp->grp[i].tile_begin) gi = i;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GroupDev G = Lp->grp[gi];
+#else
+  const GroupDev G = L.grp[0];
+#endif
+  int t = lin - G.tile_begin;
+  const int tiles_per_batch = G.tiles_m * G.tiles_n;
+  const int bidx = t / tiles_per_batch;
+  t -= bidx * tiles_per_batch;
+  int tm, tn;
+  panel_walk(t, G.tiles_m, G.tiles_n, tm, tn);
+  gemm_tile<FP8, G_>(G.g, bidx, tm * G_::BM, tn * G_::BN, G.wide_store != 0, smem);
+}
+
+// Two geometries in one launch: the 256-wide tiles of every group first, then the narrow tiles (GN_) of the columns the host
+// left over (GroupDev::n_split). Every XCD group owns a contiguous run of the wide order AND a contiguous run of the narrow
+// order and walks the wide ones first, so all eight switch to the short tiles together and the last round is (nearly) full.
+template <class GN_>
+__global__ __launch_bounds__(THREADS, 2) void gemm_mix_kernel(const Launch L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)L;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int nW = Lp->wide_total, nN = Lp->narrow_total;
+  const int cW = xcd_run_count(nW, xcd), cN = xcd_run_count(nN, xcd);
+  if (slot >= cW + cN) return;
+  const bool narrow = slot >= cW;
+  const int lin = narrow ? xcd_run_start(nN, xcd) + (slot - cW) : xcd_run_start(nW, xcd) + slot;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < RT_GEMM_MAX_GROUPS; ++i)
+    if (i < Lp->ngroups && lin >= (narrow ? Lp->grp[i].narrow_begin : Lp->grp[i].tile_begin)) gi = i;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GroupDev G = Lp->grp[gi];
+#else
+  const GroupDev G = L.grp[0];
+#endif
+  int t = lin - (narrow ? G.narrow_begin : G.tile_begin);
+  const int tn_cnt = narrow ? G.tiles_n_narrow : G.tiles_n;
+  const int tiles_per_batch = G.tiles_m * tn_cnt;
+  const int bidx = t / tiles_per_batch;
+  t -= bidx * tiles_per_batch;
+  int tm, tn;
+  panel_walk(t, G.tiles_m, tn_cnt, tm, tn);
+  if (narrow) gemm_tile<false, GN_>(G.g, bidx, tm * GN_::BM, G.n_split + tn * GN_::BN, G.wide_store != 0, smem);
+  else gemm_tile<false, Geo256>(G.g, bidx, tm * Geo256::BM, tn * Geo256::BN, G.wide_store != 0, smem);
+}
+
+// ---- host side: which geometry? --------------------------------------------------------------------------------
+int g_num_cus = 0;
+int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, v = 0;
+    g_num_cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) g_num_cus = v;
+  }
+  return g_num_cus;
+}
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+int g_tile_mode = -1;      // bit 0: 288x192 launches, bit 1: narrow tail tiles; -1 = not read yet (RT_GEMM_TILES, default 3)
+int tile_mode_now() {
+  if (g_tile_mode < 0) g_tile_mode = env_int("RT_GEMM_TILES", 3) & 3;
+  return g_tile_mode;
+}
+
+template <class K>
+int set_lds(K kern, int bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 }  // namespace
@@ -385,6 +533,8 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   const int bke = fp8 ? 128 : BK;                     // elements per K-tile
   const int al = fp8 ? 16 : 8;                        // elements per 16 bytes
   const int64_t esz = fp8 ? 1 : 2;
+  static const bool wide_on = env_int("RT_GEMM_WIDE_STORE", 1) != 0;   // A/B switches (tests and tools)
+  const int tile_mode = tile_mode_now();
   for (int i = 0; i < ngroups; ++i) {
     const rt_gemm_group& g = groups[i];
     if (!g.A || !g.W || !g.C || g.M < 1 || g.N < 1 || g.K < 1 || g.batch < 1) return RT_E_BADARG;
@@ -402,24 +552,106 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     if (g.gate && (!RT_ALIGNED(g.gate, 16) || g.gate_ld % 4)) return RT_E_ALIGN;
     if (fp8 && g.w_scale && !RT_ALIGNED(g.w_scale, 16)) return RT_E_ALIGN;
     L.grp[i].g = g;
-    L.grp[i].tiles_m = (g.M + BM - 1) / BM;
-    L.grp[i].tiles_n = (g.N + BN - 1) / BN;
-    static const bool wide_on = !(getenv("RT_GEMM_WIDE_STORE") && getenv("RT_GEMM_WIDE_STORE")[0] == '0');   // A/B switch
+    L.grp[i].tiles_m = (g.M + Geo256::BM - 1) / Geo256::BM;
+    L.grp[i].tiles_n = (g.N + Geo256::BN - 1) / Geo256::BN;
     L.grp[i].wide_store = (wide_on && !g.out_f32 && RT_ALIGNED(g.C, 16) && g.ldc % 8 == 0 && g.strideC % 8 == 0 && g.N % 8 == 0) ? 1 : 0;
     L.grp[i].tile_begin = total;
     total += L.grp[i].tiles_m * L.grp[i].tiles_n * g.batch;
   }
   static bool attr_done = false;
   if (!attr_done) {
-    for (const void* f : {reinterpret_cast<const void*>(gemm_pp_kernel<false>), reinterpret_cast<const void*>(gemm_pp_kernel<true>)}) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e != hipSuccess) return (int)e;
-    }
+    int e = set_lds(gemm_pp_kernel<false, Geo256>, Geo256::LDS_BYTES);
+    if (!e) e = set_lds(gemm_pp_kernel<true, Geo256>, Geo256::LDS_BYTES);
+    if (!e) e = set_lds(gemm_pp_kernel<false, Geo288>, Geo288::LDS_BYTES);
+    if (!e) e = set_lds(gemm_mix_kernel<Geo192>, Geo256::LDS_BYTES);
+    if (!e) e = set_lds(gemm_mix_kernel<Geo128>, Geo256::LDS_BYTES);
+    if (e) return e;
     attr_done = true;
   }
-  if (fp8) hipLaunchKernelGGL(gemm_pp_kernel<true>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
-  else hipLaunchKernelGGL(gemm_pp_kernel<false>, dim3(total), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, L);
+  hipStream_t st = (hipStream_t)stream;
+  if (fp8) {
+    hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+    return rt_hip_status();
+  }
+  const int cus = num_cus();
+  // (1) 288x192 tiles: one problem whose M x N is a whole number of them and whose 256x256 tiling leaves the last round of
+  //     workgroups emptier. Cost model: rounds x tile area, the 288x192 tile charged 4 % for its lower operand reuse.
+  if ((tile_mode & 1) && ngroups == 1 && groups[0].M % Geo288::BM == 0 && groups[0].N % Geo288::BN == 0) {
+    const rt_gemm_group& g = groups[0];
+    const int t288 = (g.M / Geo288::BM) * (g.N / Geo288::BN) * g.batch;
+    const double c256 = (double)((total + cus - 1) / cus) * Geo256::BM * Geo256::BN;
+    const double c288 = (double)((t288 + cus - 1) / cus) * Geo288::BM * Geo288::BN * 1.04;
+    if (c288 < c256) {
+      L.grp[0].tiles_m = g.M / Geo288::BM;
+      L.grp[0].tiles_n = g.N / Geo288::BN;
+      hipLaunchKernelGGL((gemm_pp_kernel<false, Geo288>), dim3(t288), dim3(THREADS), Geo288::LDS_BYTES, st, L);
+      return rt_hip_status();
+    }
+  }
+  // (2) narrow tail: a launch of several rounds whose last round is poorly filled gives up the columns of that round to 3/4- or
+  //     1/2-width tiles (same row panels). Every group is cut at the same fraction of its columns (they share N in practice).
+  if ((tile_mode & 2) && total > cus) {
+    const int rounds = (total + cus - 1) / cus;
+    const double base = (double)rounds;                                    // time in units of one 256x256 round
+    int best_w = 0, best_cols = 0;
+    double best = base * 0.985;                                            // must beat the plain tiling by 1.5 %
+    for (int w : {192, 128}) {
+      const double unit = w / 256.0 * (w == 192 ? 1.03 : 1.08);            // a narrow tile's time in 256x256 tiles (less operand reuse)
+      // give up c column-tiles (of 256) of every group to the narrow geometry
+      int min_tn = 1 << 30;
+      for (int i = 0; i < ngroups; ++i) min_tn = L.grp[i].tiles_n < min_tn ? L.grp[i].tiles_n : min_tn;
+      for (int c = 1; c < min_tn; ++c) {
+        bool ok = true;
+        int wide = 0, narrow = 0;
+        for (int i = 0; i < ngroups; ++i) {
+          const rt_gemm_group& g = groups[i];
+          const int n_split = (L.grp[i].tiles_n - c) * 256;
+          if (g.N % 256 != 0 || (g.N - n_split) % w != 0) { ok = false; break; }
+          wide += L.grp[i].tiles_m * (L.grp[i].tiles_n - c) * g.batch;
+          narrow += L.grp[i].tiles_m * ((g.N - n_split) / w) * g.batch;
+        }
+        if (!ok) continue;
+        // wide tiles run first; narrow tiles fill the CUs as they free up: list scheduling bound
+        const double tw = (double)wide / cus, tn_ = (double)narrow / cus * unit;
+        const double t = ((wide + cus - 1) / cus) + (double)((narrow + cus - 1) / cus) * unit;
+        const double lb = tw + tn_;
+        const double est = lb + (t - lb) * 0.5;                             // between the perfect and the round-by-round bound
+        if (est < best) { best = est; best_w = w; best_cols = c; }
+      }
+    }
+    if (best_w) {
+      int wide = 0, narrow = 0;
+      for (int i = 0; i < ngroups; ++i) {
+        const rt_gemm_group& g = groups[i];
+        GroupDev& G = L.grp[i];
+        G.tiles_n -= best_cols;
+        G.n_split = G.tiles_n * 256;
+        G.tiles_n_narrow = (g.N - G.n_split) / best_w;
+        G.tile_begin = wide;
+        G.narrow_begin = narrow;
+        wide += G.tiles_m * G.tiles_n * g.batch;
+        narrow += G.tiles_m * G.tiles_n_narrow * g.batch;
+      }
+      L.wide_total = wide;
+      L.narrow_total = narrow;
+      int per_xcd = 0;
+      for (int x = 0; x < 8; ++x) {
+        const int c = (wide >> 3) + (x < (wide & 7)) + (narrow >> 3) + (x < (narrow & 7));
+        per_xcd = c > per_xcd ? c : per_xcd;
+      }
+      if (best_w == 192) hipLaunchKernelGGL((gemm_mix_kernel<Geo192>), dim3(8 * per_xcd), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+      else hipLaunchKernelGGL((gemm_mix_kernel<Geo128>), dim3(8 * per_xcd), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+      return rt_hip_status();
+    }
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<false, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
   return rt_hip_status();
+}
+
+extern "C" int rt_gemm_tile_mode(int32_t mode) {
+  const int prev = tile_mode_now();
+  if (mode >= 0) g_tile_mode = mode & 3;
+  return prev;
 }
 
 extern "C" int rt_gemm_bf16(const rt_gemm_group* groups, int32_t ngroups, void* stream) {

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rt_abi_version": [],
     "rt_gemm_bf16": [C.POINTER(GemmGroup), _i32, _vp],
     "rt_gemm_fp8": [C.POINTER(GemmGroup), _i32, _vp],
+    "rt_gemm_tile_mode": [_i32],
     "rt_quantize_rows_fp8": [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp],
     "rt_layernorm_modulate_fp8": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_gemv_bf16w": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

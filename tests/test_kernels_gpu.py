@@ -106,6 +106,52 @@ def test_linear_grouped_strided(ops, gpu):
     assert float(out[:, 3 * d :].float().abs().max()) == 0.0   # padding columns untouched
 
 
+def test_linear_tile_geometries_are_bit_identical(ops, gpu):
+    """rt_gemm_bf16 picks 288x192 tiles for M x N = whole numbers of them (the single blocks' 4608 x 3072 out-projection: 256
+    tiles = 256 CUs) and cuts the poorly filled last round of a multi-round launch into 256x192 / 256x128 tiles. Every element is
+    accumulated in the same K order whatever tile computed it, so all modes must agree BIT FOR BIT — with the full epilogue,
+    grouped problems, bf16 and fp32 outputs — and with an fp32 reference."""
+    from reptext_amd import native
+
+    lib = native.load()
+    g = torch.Generator(device=gpu).manual_seed(3)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, device=gpu, generator=g) * sc).to(torch.bfloat16)
+    cases = []
+    # (a) 4608 x 3072, fp32 out + gate + residual (single-block out-projection): 288x192
+    a, w, b = rn(4608, 1024), rn(3072, 1024, sc=0.05), rn(3072)
+    gate, res = torch.randn(1, 3072, device=gpu, generator=g), torch.randn(4608, 3072, device=gpu, generator=g)
+    cases.append(("288x192 f32", lambda out: ops.linear(a, w, out, bias=b, gate=gate, res=res), torch.float32, (4608, 3072)))
+    cases.append(("288x192 bf16 gelu", lambda out: ops.linear(a, w, out, bias=b, gelu_from=1024), torch.bfloat16, (4608, 3072)))
+    # (b) grouped image + text rows, N = 12288 (ff1: 864 tiles -> last round split into half-width tiles), N = 9216 (qkv: 3/4-width)
+    x = rn(4608, 512)
+    for N in (12288, 9216):
+        wi, wt, bi, bt = rn(N, 512, sc=0.05), rn(N, 512, sc=0.05), rn(N), rn(N)
+        cases.append((f"grouped N={N}", (lambda out, wi=wi, wt=wt, bi=bi, bt=bt: ops.linear_grouped(
+            [ops.LinearProblem(x[512:], wi, out[512:], bias=bi, gelu_from=0), ops.LinearProblem(x[:512], wt, out[:512], bias=bt, gelu_from=0)])),
+            torch.bfloat16, (4608, N)))
+    # (c) one problem, ragged rows, several rounds
+    a2, w2 = rn(4000, 256), rn(5120, 256, sc=0.05)
+    cases.append(("ragged M=4000 N=5120", lambda out: ops.linear(a2, w2, out), torch.float32, (4000, 5120)))
+    prev = lib.rt_gemm_tile_mode(-1)
+    try:
+        for name, run, dt, shape in cases:
+            outs = []
+            for mode in (0, 1, 2, 3):
+                lib.rt_gemm_tile_mode(mode)
+                out = torch.full(shape, float("nan"), device=gpu, dtype=dt)
+                run(out)
+                outs.append(out)
+            assert bool(torch.isfinite(outs[0].float()).all()), name
+            for m, o in enumerate(outs[1:], 1):
+                assert torch.equal(o, outs[0]), (name, m)
+        lib.rt_gemm_tile_mode(3)
+        o = torch.empty(4608, 3072, device=gpu, dtype=torch.float32)
+        ops.linear(a, w, o)
+        assert rel_l2(o, torch.nn.functional.linear(a.float(), w.float())) < 2e-5
+    finally:
+        lib.rt_gemm_tile_mode(prev)
+
+
 def test_linear_rejects_bad_args(ops, gpu):
     from reptext_amd.native import NativeCallError
 

@@ -42,6 +42,44 @@ def bench_gemm():
     print(f"grouped qkv (4096+512)x9216x3072: {t*1e6:9.1f} us  {2*(T+Ni)*3*d*d/t/1e12:8.1f} TF/s", flush=True)
 
 
+def bench_gemm_tiles():
+    """Interleaved A/B of rt_gemm_bf16's tile modes (0 = 256x256 only, 3 = 288x192 + narrow tails) on the model's launches."""
+    from reptext_amd import native
+    lib = native.load()
+    T, Ni, d = 512, 4096, 3072
+    x = torch.randn(T + Ni, 4 * d, device=dev).to(torch.bfloat16)
+    x32 = torch.randn(T + Ni, d, device=dev)
+    gate = torch.randn(1, d, device=dev)
+    launches = []
+    w_out = (torch.randn(d, 5 * d, device=dev) * 0.02).to(torch.bfloat16)
+    a_out = torch.randn(T + Ni, 5 * d, device=dev).to(torch.bfloat16)
+    launches.append(("single out 4608x3072x15360 f32", 2 * (T + Ni) * d * 5 * d, lambda: ops.linear(a_out, w_out, x32, gate=gate, res=x32)))
+    w_f = (torch.randn(7 * d, d, device=dev) * 0.02).to(torch.bfloat16)
+    o_f = torch.empty(T + Ni, 7 * d, device=dev, dtype=torch.bfloat16)
+    launches.append(("single fused 4608x21504x3072", 2 * (T + Ni) * 7 * d * d, lambda: ops.linear(x[:, :d], w_f, o_f, gelu_from=3 * d)))
+    for name, N, K, f32 in (("qkv", 3 * d, d, False), ("ff1", 4 * d, d, False), ("ff2", d, 4 * d, True), ("out", d, d, True)):
+        wi = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        wt = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        o = x32 if f32 else torch.empty(T + Ni, N, device=dev, dtype=torch.bfloat16)
+        kw = dict(res=None)
+        def run(wi=wi, wt=wt, o=o, K=K, f32=f32):
+            if f32:
+                ops.linear_grouped([ops.LinearProblem(x[T:, :K], wi, o[T:], gate=gate, res=o[T:]), ops.LinearProblem(x[:T, :K], wt, o[:T], gate=gate, res=o[:T])])
+            else:
+                ops.linear_grouped([ops.LinearProblem(x[T:, :K], wi, o[T:]), ops.LinearProblem(x[:T, :K], wt, o[:T])])
+        launches.append((f"double {name} (4096+512)x{N}x{K}", 2 * (T + Ni) * N * K, run))
+    prev = lib.rt_gemm_tile_mode(-1)
+    for name, fl, run in launches:
+        res = {}
+        for rnd in range(3):
+            for mode in (0, 3):
+                lib.rt_gemm_tile_mode(mode)
+                res.setdefault(mode, []).append(timeit(run, iters=10, warm=2))
+        t0, t3 = min(res[0]), min(res[3])
+        print(f"{name:42s} mode0 {t0*1e6:7.1f} us {fl/t0/1e12:7.1f} TF/s | mode3 {t3*1e6:7.1f} us {fl/t3/1e12:7.1f} TF/s | {100*(t3/t0-1):+.1f} %", flush=True)
+    lib.rt_gemm_tile_mode(prev)
+
+
 def bench_gemm_fp8():
     FP8 = torch.float8_e4m3fn
     shapes = [(4608, 21504, 3072), (4096, 9216, 3072), (4096, 12288, 3072), (8192, 8192, 8192), (9728, 21504, 3072)]
@@ -110,6 +148,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("tiles", "all"):
+        bench_gemm_tiles()
     if what in ("fp8", "all"):
         bench_gemm_fp8()
     if what in ("attn", "all"):
