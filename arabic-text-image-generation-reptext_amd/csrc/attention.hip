@@ -188,27 +188,27 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
     // LDS-DMA by buffer_load ... lds: 4-SGPR descriptor per operand + the lane's loop-invariant 32-bit byte offset + the tile's
     // byte offset in an SGPR — no per-tile vector address arithmetic. num_records = 2^32-1: rows are clamped here, not by the
     // range check (the host checks (S + 64) * ld * 2 < 2^31).
-    const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, -1, 0x00020000);
+    const rt_srd_t rsrcK = rt_make_srd(Kb), rsrcV = rt_make_srd(Vb);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);          // LDS byte address of the ring
     const int tile_stride_b = BKV * (int)ld * 2;
     // One branch for the whole tile, the ragged case out of line: a taken branch costs the wave an instruction-buffer refill, and the
     // common path of the tile loop should not contain any (see RT_RARE).
     auto stage = [&](int sl, int tix, bool clamp) {
-      char* kb = smem + sl * 2 * TILE_B;
+      const uint32_t kb = lds0 + sl * 2 * TILE_B;
       if (RT_RARE(clamp)) {   // ragged last tile: rows past the end re-read row S-1 (masked later)
         const int kv0 = tix * BKV;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int row_t = (wave * 4 + p) * 4 + srow;
           const uint32_t off = ((uint32_t)(min(kv0 + row_t, S - 1) - kv0) * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)off, tix * tile_stride_b, 0, 0);
+          rt_dma16_asm(rsrcK, kb + (wave * 4 + p) * 1024, off, (uint32_t)(tix * tile_stride_b));
+          rt_dma16_asm(rsrcV, kb + TILE_B + (wave * 4 + p) * 1024, off, (uint32_t)(tix * tile_stride_b));
         }
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, LDS_PTR(kb + (wave * 4 + p) * 1024), 16, (int)soff[p], tix * tile_stride_b, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, LDS_PTR(kb + TILE_B + (wave * 4 + p) * 1024), 16, (int)soff[p], tix * tile_stride_b, 0, 0);
+          rt_dma16_asm(rsrcK, kb + (wave * 4 + p) * 1024, soff[p], (uint32_t)(tix * tile_stride_b));
+          rt_dma16_asm(rsrcV, kb + TILE_B + (wave * 4 + p) * 1024, soff[p], (uint32_t)(tix * tile_stride_b));
         }
       }
     };
@@ -223,6 +223,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       const bf16_t* qp = Qb + (int64_t)qrow * ld + 8 * hh;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+      // The loads are waited for HERE (an opaque use), once per item: left to the first use, hipcc keeps the counted vmcnt waits
+      // inside the tile loop, where they would also wait for the (uncounted, asm-issued) LDS-DMA of the next tile.
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
     f32x16 o_acc[4];

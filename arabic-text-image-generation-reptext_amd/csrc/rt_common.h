@@ -98,3 +98,20 @@ __device__ __forceinline__ void rt_lds_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+// LDS-DMA issued from inline asm: one 1-KiB piece, global (buffer descriptor + per-lane byte offset + scalar byte offset) -> LDS at
+// the wave-uniform byte address `lds_addr` + lane*16. Why asm: hipcc tracks a builtin LDS-DMA as a pending LDS WRITE and puts
+// `s_waitcnt vmcnt(0)` in front of the wave's next LDS read it cannot prove disjoint (seen in front of the first
+// ds_read_b64_tr_b16 of every attention tile, a third of the way into the tile: the copy for the NEXT tile was being waited for
+// there). An asm statement is invisible to that bookkeeping, so the copy stays in flight until OUR wait: every barrier that
+// publishes DMA-staged rows must be rt_dma_barrier() (s_waitcnt vmcnt(0) + barrier) or a counted wait. M0 (the LDS base of the
+// copy) is written in the same statement that uses it; nothing else in these kernels depends on M0.
+typedef __attribute__((ext_vector_type(4))) uint32_t rt_srd_t;
+__device__ __forceinline__ rt_srd_t rt_make_srd(const void* base) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return rt_srd_t{(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu, 0xffffffffu,
+                  0x00020000u};
+}
+__device__ __forceinline__ void rt_dma16_asm(rt_srd_t srd, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
