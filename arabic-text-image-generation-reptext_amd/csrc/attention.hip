@@ -326,22 +326,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(
       bf16x8 kA[8], kB[8], vA[4], vB[4];         // operand fragments, read one step ahead of the MFMAs that use them
       bf16x8 p00, p01, p10, p11;                 // numerators [half][k-step]
       bool pend;
-      // ---- 1: Sᵀ(h0) = K[0:32]·Qᵀ (8 MFMAs) beside the LDS-DMA issue of tile t+1 and the first reads of h1
+      // ---- 1: Sᵀ(h0) = K[0:32]·Qᵀ (8 MFMAs) beside the LDS-DMA issue of tile t+1 (one 1-KiB piece behind each MFMA: the asm
+      //         statements are placed by hand, sched_group_barrier cannot see inside them) and the first reads of h1
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) kA[ks] = kread(0, ks);
-      if (RT_USUAL(t + 1 < te)) stage(SLOT ^ 1, t + 1, (t + 2) * BKV > S);
+      const bool next_ragged = (t + 2) * BKV > S;
+      if (RT_RARE(t + 1 < te && next_ragged)) stage(SLOT ^ 1, t + 1, true);       // clamped rows: all eight pieces at once, out of line
+      const bool weave = t + 1 < te && !next_ragged;
+      {
+        const uint32_t nb = lds0 + (SLOT ^ 1) * 2 * TILE_B, so = (uint32_t)((t + 1) * tile_stride_b);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], s0, 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) kB[ks] = kread(1, ks);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int w_ = 0; w_ < 8; ++w_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if (w_ >= 4 && w_ < 7) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int ks = 0; ks < 8; ++ks) {
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], s0, 0, 0, 0);
+          if (RT_USUAL(weave)) rt_dma16_asm((ks & 1) ? rsrcV : rsrcK, nb + ((ks & 1) ? TILE_B : 0) + (wave * 4 + (ks >> 1)) * 1024, soff[ks >> 1], so);
+          if (ks >= 4 && ks < 7) kB[ks - 4] = kread(1, ks - 4);
+          RT_SB();
+        }
       }
-      RT_SB();
       // ---- 2: first 3 MFMAs of Sᵀ(h1) cover the retirement of Sᵀ(h0); row max of h0, decision (no numerators pending)
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[ks], qf[ks], s1, 0, 0, 0);
