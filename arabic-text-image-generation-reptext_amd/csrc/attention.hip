@@ -561,6 +561,12 @@ extern "C" int64_t rt_attention_ws_bytes(int32_t B, int32_t S, int32_t H) {
   return cnt_b + (int64_t)B * 8 * G.spx * 2 * REC_B;
 }
 
+// csrc/attention_v3.hip: the one-wave-per-SIMD kernel (64 query rows per wave); takes the launch when S % 256 == 0
+int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
+                        int32_t B, int32_t S, int32_t H, float scale, void* stream);
+int rt_attention_v3_mode(int mode);
+extern "C" int rt_attention_variant(int32_t mode) { return rt_attention_v3_mode(mode); }
+
 extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b,
                                 int64_t ldo, int64_t stride_ob, int32_t B, int32_t S, int32_t H, float scale,
                                 void* ws, int64_t ws_bytes, void* stream) {
@@ -571,6 +577,10 @@ extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, voi
   if (ld < (int64_t)H * DH || ldo < (int64_t)H * DH) return RT_E_SHAPE;
   if ((int64_t)(S + BKV) * ld * 2 >= (int64_t)1 << 31) return RT_E_SHAPE;      // per-tile byte offsets are 32-bit
   if ((int64_t)((S + BQ - 1) / BQ) * H * ((S + BKV - 1) / BKV + 1) * slots_per_xcd() >= ((int64_t)1 << 31)) return RT_E_SHAPE;   // 32-bit run arithmetic
+  {
+    const int r = rt_attention_v3_try(q, k, v, o, ld, stride_b, ldo, stride_ob, B, S, H, scale, stream);
+    if (r != 0) return r == 1 ? RT_OK : r;
+  }
   const int64_t need = rt_attention_ws_bytes(B, S, H);
   const bool split = ws != nullptr && need > 0;
   if (split && (ws_bytes < need || !RT_ALIGNED(ws, 256))) return RT_E_BADARG;

@@ -1,0 +1,465 @@
+// attention_v3 — the joint attention of the MMDiT blocks (same math and interface as csrc/attention.hip: softmax(Q·Kᵀ·scale)·V,
+// head dim 128, bf16 in/out; torch SDPA as reached from controlnet_flux.py:343-348,376-380 and PIPE:1092)
+// restructured for ONE wave per SIMD with the whole 512-entry register file:
+//
+//   * a workgroup = 4 waves = 256 query rows of one (batch, head); a wave owns 64 rows = two 32-row query blocks (a, b) that
+//     SHARE every K and V fragment it reads from LDS: half the LDS bytes per MFMA of the 32-rows-per-wave kernel;
+//   * Oᵀ (2 x 4 accumulators of 32x32: 128 registers) and the Q fragments (64 registers) live in the ACCUMULATOR half of the
+//     register file for the whole item, the scores, numerators and K / Vᵀ fragments in the architectural half. hipcc decides
+//     per FUNCTION whether MFMA results go to AGPRs or VGPRs (at a 512-register budget: all to AGPRs, and it then copies every
+//     score back with v_accvgpr_read — 576 copies per tile in a trial build), so the MFMAs here are inline asm with the register
+//     class of each operand spelled out: scores "+v" (they feed the VALU), Oᵀ "+a", Q "a";
+//   * the tile loop is software-pipelined by 32-key halves over four groups of 16 MFMAs, each MFMA followed by its share of the
+//     vector work (one softmax element = fma, exp2, add, half a cvt_pk; one running-max step; an LDS read; now and then an
+//     LDS-DMA piece), in source order with a scheduling fence per MFMA gap — with a single wave per SIMD nothing else hides
+//     vector work behind the matrix pipe:
+//         G1  Sᵀ(k0,t)  = K·Qᵀ      ∥ numerators 16..31 of k1(t-1), Vᵀ(k1,t-1) fragments, 4 DMA pieces of tile t+1
+//         G2  Oᵀ += Vᵀ·Pᵀ (k1,t-1)   ∥ numerators 0..15 of k0(t) (speculative, against the running max), row max of k0(t), K(k1,t)
+//         G3  Sᵀ(k1,t)              ∥ max exchange + decision for k0(t), numerators 16..31 of k0(t), Vᵀ(k0,t) fragments
+//         G4  Oᵀ += Vᵀ·Pᵀ (k0,t)     ∥ numerators 0..15 of k1(t) (speculative), row max of k1(t), K(k0,t+1), 4 DMA pieces of t+2
+//     The numerators of a half are started against the running max m before that half's own maximum is known; the decision
+//     (two gaps into the next group) only acts when some row's maximum outgrew m by more than 2^6: it then rescales O and l and
+//     recomputes the 16 speculative numerators (rare after the first tiles). Every numerator that reaches an MFMA was formed
+//     against the maximum O is normalised with.
+//   * K/V tiles of 64 keys arrive by LDS-DMA (asm-issued: see rt_dma16_asm) into a 3-deep ring, one barrier per tile: the barrier
+//     in front of G4(t) publishes tile t+1 (copied a whole tile earlier) and frees the stage of tile t-1 for tile t+2.
+//
+// Applies when S is a multiple of 256 (every shape of the pipelines at 1024² / 1536² / 256²); other shapes run attention.hip.
+#include "rt_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int DH = 128;
+constexpr int BQ3 = 256;             // query rows per work item
+constexpr int BKV = 64;
+constexpr int TILE_B = BKV * DH * 2; // 16 KiB (one K or V tile)
+constexpr int STAGE_B = 2 * TILE_B;  // K | V
+constexpr int NSTAGE = 3;
+constexpr int V3_THREADS = 256;
+constexpr float RESCALE_THR = 6.0f;
+
+__device__ __forceinline__ int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// ---- the accumulator half of the register file is OWNED by the asm statements of this file -------------------------------------
+// O fragment f = d block * 2 + query block lives in a[16f : 16f+15], Q fragment i = query block * 8 + k-step in a[128+4i : 131+4i]
+// (attention_v3_regs.h). The statements name those registers literally and list them as clobbers — which is also what makes the
+// kernel descriptor allocate them. hipcc must never put a value of its own there: this file is built with
+// -mllvm -amdgpu-spill-vgpr-to-agpr=0 (no VGPR spills into AGPRs) and contains no "a"-constrained operand; the Makefile audits
+// the object for 0 spills / 0 scratch.
+#include "attention_v3_regs.h"
+#define V3_EACH8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define V3_EACH16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+// Oᵀ fragment f += Vᵀ fragment · numerators
+__device__ __forceinline__ void mfma_o(int f, const bf16x8& v, const bf16x8& p) {
+  switch (f) {
+#define V3_C(F) case F: asm volatile("v_mfma_f32_32x32x16_bf16 " V3_OREG_##F ", %0, %1, " V3_OREG_##F ::"v"(v), "v"(p) : V3_OCL_##F); break;
+    V3_EACH8(V3_C)
+#undef V3_C
+  }
+}
+// scores (architectural registers: they feed the VALU) = / += K fragment · Q fragment i
+__device__ __forceinline__ void mfma_s0(f32x16& c, const bf16x8& k, int i) {
+  switch (i) {
+#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", 0" : "=&v"(c) : "v"(k)); break;
+    V3_EACH16(V3_C)
+#undef V3_C
+  }
+}
+__device__ __forceinline__ void mfma_s(f32x16& c, const bf16x8& k, int i) {
+  switch (i) {
+#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", %0" : "+v"(c) : "v"(k)); break;
+    V3_EACH16(V3_C)
+#undef V3_C
+  }
+}
+__device__ __forceinline__ void q_write(int i, const bf16x8& q) {
+  const u32x4 w = __builtin_bit_cast(u32x4, q);
+  switch (i) {
+#define V3_C(I) case I: asm volatile(V3_QWRITE_##I ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : V3_QCL_##I); break;
+    V3_EACH16(V3_C)
+#undef V3_C
+  }
+}
+__device__ __forceinline__ void o_zero(int f) {
+  switch (f) {
+#define V3_C(F) case F: asm volatile(V3_OZERO_##F ::: V3_OCL_##F); break;
+    V3_EACH8(V3_C)
+#undef V3_C
+  }
+}
+__device__ __forceinline__ void o_scale(int f, float alpha) {
+  float tmp;
+  switch (f) {
+#define V3_C(F) case F: asm volatile(V3_OSCALE_##F : "=&v"(tmp) : "v"(alpha) : V3_OCL_##F); break;
+    V3_EACH8(V3_C)
+#undef V3_C
+  }
+}
+__device__ __forceinline__ f32x16 o_read(int f) {
+  float x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+  switch (f) {
+#define V3_C(F) case F: asm volatile(V3_OREAD_##F : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=v"(x8), "=v"(x9), "=v"(x10), "=v"(x11), "=v"(x12), "=v"(x13), "=v"(x14), "=v"(x15)); break;
+    V3_EACH8(V3_C)
+#undef V3_C
+  }
+  return f32x16{x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15};
+}
+#define V3_SB() __builtin_amdgcn_sched_barrier(0)
+// an opaque use+def: nothing that reads x can be scheduled above this point (MFMA results need 12 wait states before a VALU read;
+// the asm MFMAs are invisible to hipcc's hazard recogniser, so the distance is kept by ORDER: two MFMAs always sit in between)
+#define V3_PIN(x) asm volatile("" : "+v"(x))
+
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+__device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+struct V3Geom {
+  int S, H, nqb, ntiles, NI;   // NI = H * nqb work items per batch entry
+  int spx;                     // workgroups per XCD group (one per CU)
+};
+
+__global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                     const bf16_t* __restrict__ V, bf16_t* O, int64_t ld, int64_t stride_b,
+                                                                     int64_t ldo, int64_t stride_ob, float scale_log2, const V3Geom G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][K|V]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int ntiles = G.ntiles;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, b = (int)blockIdx.y;
+  // items of this XCD group: a contiguous run (whole heads stay in one XCD's L2)
+  const int base = G.NI >> 3, extra = G.NI & 7;
+  const int cnt = base + (xcd < extra ? 1 : 0);
+  const int start = xcd * base + (xcd < extra ? xcd : extra);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+
+  // ---- per-lane constants
+  const int srow = lane >> 4, spc = lane & 15;          // staging: wave w stages pieces 4w..4w+3 (4 rows each) of K and of V
+  uint32_t soff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row_t = (wave * 4 + p) * 4 + srow;
+    soff[p] = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
+  }
+  int kp[8];                                             // K row read: row 32kb + l31, chunk 2ks + hh
+  {
+    const int ksw = swz(l31);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kp[ks] = (int)lds0 + l31 * 256 + (((2 * ks + hh) ^ ksw) << 4);
+  }
+  const int tq = (lane >> 2) & 3, tp = lane & 3, tg1 = (lane >> 4) & 1;
+  int vp[2][4];                                          // Vᵀ transposed reads (see attention.hip)
+  {
+    const int cl = tg1 * 2 + (tp >> 1);
+    const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      vp[0][dt] = (int)lds0 + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
+      vp[1][dt] = (int)lds0 + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
+    }
+  }
+  const int tile_stride_b = BKV * (int)ld * 2;
+
+  for (int it = slot; it < cnt; it += G.spx) {
+    const int item = start + it;
+    const int head = item / G.nqb;
+    const int q0 = (item - head * G.nqb) * BQ3;
+    const bf16_t* Qb = Q + b * stride_b + head * DH;
+    const rt_srd_t rsrcK = rt_make_srd(K + b * stride_b + head * DH), rsrcV = rt_make_srd(V + b * stride_b + head * DH);
+    auto dma_piece = [&](int st, int tix, int i) {      // piece i of 8: K pieces 0..3, V pieces 4..7 of this wave
+      const uint32_t dst = lds0 + st * STAGE_B + ((i & 4) ? TILE_B : 0) + (wave * 4 + (i & 3)) * 1024;
+      rt_dma16_asm((i & 4) ? rsrcV : rsrcK, dst, soff[i & 3], (uint32_t)(tix * tile_stride_b));
+    };
+
+    __syncthreads();                                     // the previous item's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(0, 0, i);
+    if (ntiles > 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_piece(1, 1, i);
+    }
+    // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7] for its row of block a and of block b
+    {
+      const bf16_t* qp = Qb + (int64_t)(q0 + wave * 64 + l31) * ld + 8 * hh;
+      bf16x8 qa[8], qb[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        qa[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        qb[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ld + ks * 16);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { q_write(ks, qa[ks]); q_write(8 + ks, qb[ks]); }     // parked in a[128:191] for the whole item
+#pragma unroll
+      for (int f = 0; f < 8; ++f) o_zero(f);
+      asm volatile("s_nop 7" ::: "memory");               // accvgpr writes settle before the first MFMA reads them
+    }
+    float mA = -INFINITY, mB = -INFINITY, lA = 0.f, lB = 0.f;     // running max (log2 domain) and row sum per query block
+
+    f32x16 sAa, sAb, sBa, sBb;          // scores: key half k0 (A) / k1 (B) x query block a / b
+    bf16x8 pA[2][2], pB[2][2];          // numerators [query block][k-step of 16 keys]
+    bf16x8 kf[8], vf[8];                // K fragments of one 32-key half [ks]; Vᵀ fragments of one half [s2*4 + dt]
+    float lsnapA = 0.f, lsnapB = 0.f;   // row sums before a half's speculative numerators were added
+    float mxa0, mxa1, mxb0, mxb1;       // running-max chains
+
+    // one softmax element o of a half (order: k-step, query block, j): numerator against the CURRENT running max
+    // The opaque uses pin every step where it is written: left alone, LLVM sinks the speculative numerators of a half below
+    // the decision branch that may redo them (they are only NEEDED after it) — all 16 in one lump, with no MFMA beside them.
+    auto elem = [&](int o, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7, r = 8 * ks + j;
+      if (qb) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(Sb[r], scale_log2, -mB));
+        asm volatile("" : "+v"(p));
+        lB += p;
+        asm volatile("" : "+v"(lB));
+        P[1][ks][j] = (__bf16)p;
+        if (j & 1) asm volatile("" : "+v"(P[1][ks]));
+      } else {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(Sa[r], scale_log2, -mA));
+        asm volatile("" : "+v"(p));
+        lA += p;
+        asm volatile("" : "+v"(lA));
+        P[0][ks][j] = (__bf16)p;
+        if (j & 1) asm volatile("" : "+v"(P[0][ks]));
+      }
+    };
+    // step k (0..7) of the max chain over the 16 scores of one fragment
+    auto maxstep = [&](int k, const f32x16& s, float& m0, float& m1) __attribute__((always_inline)) {
+      if (k == 0) m0 = max3f(s[0], s[1], s[2]);
+      else if (k == 1) m1 = max3f(s[3], s[4], s[5]);
+      else if (k == 2) m0 = max3f(m0, s[6], s[7]);
+      else if (k == 3) m1 = max3f(m1, s[8], s[9]);
+      else if (k == 4) m0 = max3f(m0, s[10], s[11]);
+      else if (k == 5) m1 = max3f(m1, s[12], s[13]);
+      else if (k == 6) m0 = max3f(m0, s[14], s[15]);
+      else m0 = fmaxf(m0, m1);
+    };
+    // both halves of a row's maximum (lanes l and l+32) through one v_permlane32_swap (asm: see attention.hip), scaled to log2 units
+    auto exchange = [&](float mx) __attribute__((always_inline)) -> float {
+      unsigned xa = __builtin_bit_cast(unsigned, mx), xb = xa;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
+      return fmaxf(__builtin_bit_cast(float, xa), __builtin_bit_cast(float, xb)) * scale_log2;
+    };
+    // Decision for one half whose first 16 numerators (P[.][0]) were formed speculatively against (mA, mB): when a row's maximum
+    // outgrew the running one by more than the threshold, move the maxima, rescale l (from its snapshot) and O, and redo those 16.
+    auto decide = [&](float mxra, float mxrb, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      if (__builtin_expect(!!__any((mxra - mA > RESCALE_THR) | (mxrb - mB > RESCALE_THR)), 0)) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // O's last MFMA has retired before the copies below read it
+        const float nA = fmaxf(mA, mxra), nB = fmaxf(mB, mxrb);
+        const float alA = __builtin_amdgcn_exp2f(mA - nA), alB = __builtin_amdgcn_exp2f(mB - nB);   // first tile: exp2(-inf) = 0
+        mA = nA; mB = nB;
+        lA = lsnapA * alA; lB = lsnapB * alB;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) o_scale(f, (f & 1) ? alB : alA);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) elem(o, Sa, Sb, P);
+      }
+    };
+    // LDS read addresses of the stage in use: ka = K rows of one stage, va = Vᵀ blocks of one stage. They are moved to the next
+    // stage once per tile (16 integer adds, as fillers) and made opaque, so every read is base register + immediate.
+    int ka[8], va[8];
+    auto set_ka = [&](int i, int sbase) __attribute__((always_inline)) { ka[i] = kp[i] + sbase; asm volatile("" : "+v"(ka[i])); };
+    auto set_va = [&](int i, int sbase) __attribute__((always_inline)) { va[i] = vp[i >> 2][i & 3] + sbase; asm volatile("" : "+v"(va[i])); };
+    auto kread = [&](int kb, int ks) __attribute__((always_inline)) -> bf16x8 {
+      return *(const __attribute__((address_space(3))) bf16x8*)((lds_cptr)(uintptr_t)(uint32_t)(ka[ks] + kb * 8192));
+    };
+    auto vread = [&](int kb, int s2, int dt) __attribute__((always_inline)) -> bf16x8 {
+      const s16x4 lo = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[dt] + kb * 8192 + s2 * 4096));
+      const s16x4 hi = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[4 + dt] + kb * 8192 + s2 * 4096));
+      return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // Sᵀ of one 32-key half (16 MFMAs: k-step x query block), one filler slot per gap
+    auto qk_group = [&](f32x16& Sa, f32x16& Sb, auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int ks = g >> 1;
+        if (g == 0) mfma_s0(Sa, kf[0], 0);
+        else if (g == 1) mfma_s0(Sb, kf[0], 8);
+        else if (g & 1) mfma_s(Sb, kf[ks], 8 + ks);
+        else mfma_s(Sa, kf[ks], ks);
+        filler(g);
+        V3_SB();
+      }
+    };
+    // Oᵀ += Vᵀ·Pᵀ for one 32-key half (16 MFMAs: k-step x d block x query block)
+    auto pv_group = [&](bf16x8 (&P)[2][2], auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int s2 = g >> 3, dt = (g >> 1) & 3;
+        mfma_o(dt * 2 + (g & 1), vf[s2 * 4 + dt], P[g & 1][s2]);
+        filler(g);
+        V3_SB();
+      }
+    };
+
+    // ---------------------------------------------------------------------------------------------- the tile loop
+    // stage of tile t = t % 3; tiles 0 and 1 are in flight (the waits of the Q loads above already covered them: in-order counter)
+    float rka = 0.f, rkb = 0.f;        // row maxima (this lane's 16 keys) of the half whose decision is pending
+    auto tile = [&](auto first_c, auto last_c, int t) __attribute__((always_inline)) {
+      constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
+      const int sb = (t % NSTAGE) * STAGE_B;
+      const int sbn = ((t + 1) % NSTAGE) * STAGE_B;
+      const int stp = (t + 2) % NSTAGE;                            // stage of tile t-1 (= of tile t+2)
+      const bool more2 = t + 2 < ntiles;
+      float ea = 0.f, eb = 0.f;
+      // ---- G1: Sᵀ(k0,t) ∥ decision + numerators 16..31 of k1(t-1), Vᵀ(k1,t-1) fragments
+      qk_group(sAa, sAb, [&](int g) __attribute__((always_inline)) {
+        if constexpr (!first) {
+          if (g == 0) ea = exchange(rka);
+          if (g == 1) { eb = exchange(rkb); decide(ea, eb, sBa, sBb, pB); }
+          if (g >= 2) elem(14 + g, sBa, sBb, pB);
+          if (g == 2 || g == 3) elem(g == 2 ? 30 : 31, sBa, sBb, pB);
+          if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(1, i >> 2, i & 3); }
+        }
+      });
+      // ---- G2: PV(k1,t-1) ∥ speculative numerators 0..15 of k0(t), max chains of k0(t), K(k1,t) fragments
+      lsnapA = lA; lsnapB = lB;
+      if constexpr (!first) {
+        pv_group(pB, [&](int g) __attribute__((always_inline)) {
+          if (g == 0) V3_PIN(sAa);                    // two MFMAs behind its last accumulation (G1 g = 14): safe to read from here on
+          if (g == 1) V3_PIN(sAb);
+          if (g >= 1) elem(g - 1, sAa, sAb, pA);      // elements 0..14; element 15 below
+          if (g == 15) elem(15, sAa, sAb, pA);
+          if (g >= 1 && g < 9) maxstep(g - 1, sAa, mxa0, mxa1);
+          if (g >= 8) maxstep(g - 8, sAb, mxb0, mxb1);
+          if (g & 1) kf[g >> 1] = kread(1, g >> 1); else set_va(g >> 1, sb);
+        });
+      } else {
+        // first tile: no PV to overlap with; the scores of k0 need their 12 wait states before the VALU reads them
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        V3_PIN(sAa); V3_PIN(sAb);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { maxstep(g, sAa, mxa0, mxa1); maxstep(g, sAb, mxb0, mxb1); }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { kf[ks] = kread(1, ks); set_va(ks, sb); }
+      }
+      rka = mxa0; rkb = mxb0;                          // maxstep 7 leaves a chain's result in its first variable
+      V3_SB();
+      // ---- G3: Sᵀ(k1,t) ∥ exchange + decision for k0(t), numerators 16..31 (first tile: all 32) of k0(t), Vᵀ(k0,t) fragments
+      qk_group(sBa, sBb, [&](int g) __attribute__((always_inline)) {
+        if (g == 0) ea = exchange(rka);
+        if (g == 1) {
+          eb = exchange(rkb);
+          if constexpr (first) { mA = fmaxf(mA, ea); mB = fmaxf(mB, eb); }      // nothing accumulated yet: just fix the maxima
+          else decide(ea, eb, sAa, sAb, pA);
+        }
+        if constexpr (first) {
+          if (g >= 2) { elem(2 * (g - 2), sAa, sAb, pA); elem(2 * (g - 2) + 1, sAa, sAb, pA); }
+          if (g == 14) { elem(28, sAa, sAb, pA); elem(29, sAa, sAb, pA); }
+          if (g == 15) { elem(30, sAa, sAb, pA); elem(31, sAa, sAb, pA); }
+        } else {
+          if (g >= 2) elem(14 + g, sAa, sAb, pA);
+          if (g == 2 || g == 3) elem(g == 2 ? 30 : 31, sAa, sAb, pA);
+        }
+        if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(0, i >> 2, i & 3); } else { set_ka(g >> 1, sbn); }
+      });
+      // ---- barrier: tile t+1 has landed everywhere, the stage of tile t-1 is free
+      if constexpr (!last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        V3_SB();
+      }
+      // ---- G4: PV(k0,t) ∥ speculative numerators 0..15 of k1(t), max chains of k1(t), K(k0,t+1) fragments, DMA of tile t+2
+      lsnapA = lA; lsnapB = lB;
+      pv_group(pA, [&](int g) __attribute__((always_inline)) {
+        if (g == 0) V3_PIN(sBa);
+        if (g == 1) V3_PIN(sBb);
+        if (g >= 1) elem(g - 1, sBa, sBb, pB);
+        if (g == 15) elem(15, sBa, sBb, pB);
+        if (g >= 1 && g < 9) maxstep(g - 1, sBa, mxa0, mxa1);
+        if (g >= 8) maxstep(g - 8, sBb, mxb0, mxb1);
+        if constexpr (!last) {
+          if (g & 1) kf[g >> 1] = kread(0, g >> 1);
+          if ((g & 1) == 0 && more2) dma_piece(stp, t + 2, g >> 1);
+        }
+      });
+      rka = mxa0; rkb = mxb0;
+      if constexpr (last) {
+        // ---- drain: decision + numerators 16..31 of k1(t), then PV(k1,t)
+        V3_SB();
+        const float ea2 = exchange(rka), eb2 = exchange(rkb);
+        decide(ea2, eb2, sBa, sBb, pB);
+#pragma unroll
+        for (int o = 16; o < 32; ++o) elem(o, sBa, sBb, pB);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vf[(i >> 2) * 4 + (i & 3)] = vread(1, i >> 2, i & 3);
+        V3_SB();
+        pv_group(pB, [&](int) __attribute__((always_inline)) {});
+      }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    __syncthreads();                                     // tile 0 has landed everywhere (every wave's Q-load waits covered its DMA)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { set_ka(ks, 0); kf[ks] = kread(0, ks); }
+    tile(TT{}, FF{}, 0);
+    for (int t = 1; t + 1 < ntiles; ++t) tile(FF{}, FF{}, t);
+    tile(FF{}, TT{}, ntiles - 1);
+
+    // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMA has retired before its accumulators are read
+    const float invA = 1.0f / (lA + __shfl_xor(lA, 32)), invB = 1.0f / (lB + __shfl_xor(lB, 32));
+    bf16_t* orow = O + b * stride_ob + (int64_t)(q0 + wave * 64 + l31) * ldo + head * DH;
+    {
+      f32x16 oA[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oA[dt] = o_read(dt * 2);
+      rt_store_o_rows(orow, true, hh, oA, invA);
+    }
+    {
+      f32x16 oB[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oB[dt] = o_read(dt * 2 + 1);
+      rt_store_o_rows(orow + 32 * ldo, true, hh, oB, invB);
+    }
+  }
+}
+
+int g_v3_mode = -1;       // 1 = use attention_v3 where it applies (RT_ATTN_V3, default 1)
+
+}  // namespace
+
+// Called by rt_attention_fwd: returns 1 when the launch was taken over, 0 when the shape is left to attention.hip, < 0 / hipError on failure.
+int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
+                        int32_t B, int32_t S, int32_t H, float scale, void* stream) {
+  if (g_v3_mode < 0) {
+    const char* e = getenv("RT_ATTN_V3");
+    g_v3_mode = e ? atoi(e) : 1;
+  }
+  if (!g_v3_mode || S % BQ3 != 0 || (ldo % 8) || (stride_ob % 8) || !RT_ALIGNED(o, 16)) return 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int x = 0;
+    if (hipDeviceGetAttribute(&x, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && x > 0) cus = x;
+  }
+  V3Geom G;
+  G.S = S; G.H = H; G.nqb = S / BQ3; G.ntiles = S / BKV; G.NI = H * G.nqb;
+  G.spx = cus / 8 > 0 ? cus / 8 : 1;
+  const int lds = NSTAGE * STAGE_B;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int per = (G.NI + 7) / 8;
+  const int slots = per < G.spx ? per : G.spx;
+  hipLaunchKernelGGL(attention_v3_kernel, dim3(8 * slots, B), dim3(V3_THREADS), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, scale * 1.4426950408889634f, G);
+  const int st = rt_hip_status();
+  return st == RT_OK ? 1 : st;
+}
+
+int rt_attention_v3_mode(int mode) {
+  if (g_v3_mode < 0) {
+    const char* e = getenv("RT_ATTN_V3");
+    g_v3_mode = e ? atoi(e) : 1;
+  }
+  const int prev = g_v3_mode;
+  if (mode >= 0) g_v3_mode = mode;
+  return prev;
+}

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_layernorm_modulate": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_qk_rmsnorm_rope": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_ws_bytes": [_i32, _i32, _i32],
+    "rt_attention_variant": [_i32],
     "rt_attention_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
     "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
     "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],

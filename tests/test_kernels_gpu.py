@@ -268,6 +268,49 @@ def test_attention_online_softmax_rescale(ops, gpu):
     assert float((out.float().cpu()[0, 17] - ref[0, 17]).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("B,S,H", [(1, 256, 2), (2, 768, 3), (1, 1024, 24), (1, 4608, 4)])
+def test_attention_v3_variant(ops, gpu, B, S, H):
+    """csrc/attention_v3.hip (one wave per SIMD, 64 query rows per wave, O and Q in asm-owned accumulator registers, speculative
+    numerators with a deferred decision) on the shapes it takes (S % 256 == 0): against the fp32 oracle, against attention.hip on
+    the same buffers, with a key that spikes LATE for one query row in each 32-row block position (the rescale path must fire
+    in both query blocks of a wave, in either key half), bitwise repeatable, in place over q."""
+    from reptext_amd import native
+
+    lib = native.load()
+    d = H * 128
+    g = torch.Generator().manual_seed(S + H)
+    qkv = bf16r(torch.randn(B, S, 3 * d, generator=g))
+    qkv[..., :d] *= 2.0
+    q, k, v = (qkv[..., i * d : (i + 1) * d].reshape(B, S, H, 128) for i in range(3))
+    # spikes: query rows 5 (block a of wave 0) and 40 (block b), 200 (wave 3): keys late in the sequence, first / second half of a tile
+    for qrow, krow in ((5, S - 70), (40, S - 20), (200, S // 2 + 33)):
+        k[0, krow, 0] = q[0, qrow, 0] * 3.0
+    qkv = torch.cat([q.reshape(B, S, d), k.reshape(B, S, d), v.reshape(B, S, d)], dim=-1)
+    ref = orc.attention(q, k, v)
+    dq = qkv.to(gpu, torch.bfloat16)
+    prev = lib.rt_attention_variant(-1)
+    try:
+        lib.rt_attention_variant(1)
+        out3 = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
+        ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], out3, H)
+        again = torch.empty_like(out3)
+        ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], again, H)
+        lib.rt_attention_variant(0)
+        out1 = torch.empty_like(out3)
+        ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], out1, H)
+        e3, e1, e31 = rel_l2(out3.float().cpu(), ref), rel_l2(out1.float().cpu(), ref), rel_l2(out3.float(), out1.float())
+        print(f"attention v3 B={B} S={S} H={H}: {e3:.3e} vs fp32 oracle (attention.hip {e1:.3e}); v3 vs attention.hip {e31:.3e}")
+        assert bool(torch.isfinite(out3.float()).all()) and e3 < 5e-3 and torch.equal(out3, again)
+        for qrow in (5, 40, 200):
+            assert float((out3.float().cpu()[0, qrow, :128] - ref.reshape(B, S, d)[0, qrow, :128]).abs().max()) < 0.08, qrow
+        lib.rt_attention_variant(1)
+        inplace = dq.clone()
+        ops.attention(inplace[..., :d], inplace[..., d : 2 * d], inplace[..., 2 * d :], inplace[..., :d], H)
+        assert torch.equal(inplace[..., :d], out3)
+    finally:
+        lib.rt_attention_variant(prev)
+
+
 # ------------------------------------------------------------------------------------------- elementwise
 def test_euler_pack_cast_mask(ops, gpu):
     g = torch.Generator().manual_seed(2)

@@ -101,12 +101,23 @@ def bench_gemm_fp8():
 
 
 def bench_attn():
-    for B, S, H in [(1, 4608, 24), (1, 768, 24), (1, 9728, 24)]:
+    """Interleaved A/B of the two attention kernels (variant 0 = attention.hip, 1 = attention_v3.hip where it applies)."""
+    from reptext_amd import native
+    lib = native.load()
+    prev = lib.rt_attention_variant(-1)
+    for B, S, H in [(1, 4608, 24), (1, 4096, 32), (4, 4608, 24), (1, 768, 24), (1, 9728, 24)]:
         d = H * 128
         qkv = torch.randn(B, S, 3 * d, device=dev).to(torch.bfloat16)
         out = torch.empty(B, S, d, device=dev, dtype=torch.bfloat16)
-        t = timeit(lambda: ops.attention(qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:], out, H))
-        print(f"attn B={B} S={S} H={H}: {t*1e6:9.1f} us  {4*B*H*S*S*128/t/1e12:8.1f} TF/s", flush=True)
+        res = {}
+        for rnd in range(3):
+            for var in (0, 1):
+                lib.rt_attention_variant(var)
+                res.setdefault(var, []).append(timeit(lambda: ops.attention(qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:], out, H), iters=10, warm=2))
+        fl = 4 * B * H * S * S * 128
+        t0, t1 = min(res[0]), min(res[1])
+        print(f"attn B={B} S={S} H={H}: attention.hip {t0*1e6:8.1f} us {fl/t0/1e12:7.1f} TF/s | v3 {t1*1e6:8.1f} us {fl/t1/1e12:7.1f} TF/s | {100*(t1/t0-1):+.1f} %", flush=True)
+    lib.rt_attention_variant(prev)
 
 
 def bench_attn_fp8():
