@@ -549,21 +549,24 @@ AttnGeom make_geom(int S, int H, bool want_split) {
 
 // Workspace of the key-split tail for (B, S, H) on the current device: item counters (zero before first use; the kernel
 // leaves them zero) followed by the partial records. 0 when no item of this shape would be split.
+int64_t rt_attention_v3_ws_bytes(int32_t B, int32_t S, int32_t H);
 extern "C" int64_t rt_attention_ws_bytes(int32_t B, int32_t S, int32_t H) {
   if (B < 1 || S < 1 || H < 1) return 0;
   static const bool off = getenv("RT_ATTN_SPLIT") && getenv("RT_ATTN_SPLIT")[0] == '0';
   if (off) return 0;
+  const int64_t need3 = rt_attention_v3_ws_bytes(B, S, H);     // the larger of the two kernels' needs: either may serve the call
   const AttnGeom G = make_geom(S, H, true);
   bool any = false;
   for (int x = 0; x < 8; ++x) any = any || group_cut(G, x).rem > 0;
-  if (!any) return 0;
+  if (!any) return need3;
   const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
-  return cnt_b + (int64_t)B * 8 * G.spx * 2 * REC_B;
+  const int64_t need = cnt_b + (int64_t)B * 8 * G.spx * 2 * REC_B;
+  return need > need3 ? need : need3;
 }
 
 // csrc/attention_v3.hip: the one-wave-per-SIMD kernel (64 query rows per wave); takes the launch when S % 256 == 0
 int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
-                        int32_t B, int32_t S, int32_t H, float scale, void* stream);
+                        int32_t B, int32_t S, int32_t H, float scale, void* ws, int64_t ws_bytes, void* stream);
 int rt_attention_v3_mode(int mode);
 extern "C" int rt_attention_variant(int32_t mode) { return rt_attention_v3_mode(mode); }
 
@@ -578,7 +581,7 @@ extern "C" int rt_attention_fwd(const void* q, const void* k, const void* v, voi
   if ((int64_t)(S + BKV) * ld * 2 >= (int64_t)1 << 31) return RT_E_SHAPE;      // per-tile byte offsets are 32-bit
   if ((int64_t)((S + BQ - 1) / BQ) * H * ((S + BKV - 1) / BKV + 1) * slots_per_xcd() >= ((int64_t)1 << 31)) return RT_E_SHAPE;   // 32-bit run arithmetic
   {
-    const int r = rt_attention_v3_try(q, k, v, o, ld, stride_b, ldo, stride_ob, B, S, H, scale, stream);
+    const int r = rt_attention_v3_try(q, k, v, o, ld, stride_b, ldo, stride_ob, B, S, H, scale, ws, ws_bytes, stream);
     if (r != 0) return r == 1 ? RT_OK : r;
   }
   const int64_t need = rt_attention_ws_bytes(B, S, H);

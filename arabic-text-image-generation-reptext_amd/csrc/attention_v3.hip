@@ -46,16 +46,19 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 // ---- the accumulator half of the register file is OWNED by the asm statements of this file -------------------------------------
 // O fragment f = d block * 2 + query block lives in a[16f : 16f+15], Q fragment i = query block * 8 + k-step in a[128+4i : 131+4i]
 // (attention_v3_regs.h). The statements name those registers literally and list them as clobbers — which is also what makes the
-// kernel descriptor allocate them. hipcc must never put a value of its own there: this file is built with
-// -mllvm -amdgpu-spill-vgpr-to-agpr=0 (no VGPR spills into AGPRs) and contains no "a"-constrained operand; the Makefile audits
-// the object for 0 spills / 0 scratch.
+// kernel descriptor allocate them. hipcc must never put a value of its own there. A statement that only READS them (the score
+// MFMAs read Q) has no way to say so, and hipcc did park two long-lived values in a128 / a130 across the whole tile loop in one
+// build: EVERY statement below therefore lists ALL of a0..a191 as clobbered, so no value of the compiler's can be live in them
+// across any MFMA. This file is built with -mllvm -amdgpu-spill-vgpr-to-agpr=0 (no VGPR spills into AGPRs) and contains no
+// "a"-constrained operand; `make audit_v3` (tools/audit_v3_asm.py, also run by tests/test_capi_and_layout.py) rejects a build
+// with a VGPR spill, scratch, or any compiler-generated v_accvgpr_* naming a0..a191.
 #include "attention_v3_regs.h"
 #define V3_EACH8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define V3_EACH16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 // Oᵀ fragment f += Vᵀ fragment · numerators
 __device__ __forceinline__ void mfma_o(int f, const bf16x8& v, const bf16x8& p) {
   switch (f) {
-#define V3_C(F) case F: asm volatile("v_mfma_f32_32x32x16_bf16 " V3_OREG_##F ", %0, %1, " V3_OREG_##F ::"v"(v), "v"(p) : V3_OCL_##F); break;
+#define V3_C(F) case F: asm volatile("v_mfma_f32_32x32x16_bf16 " V3_OREG_##F ", %0, %1, " V3_OREG_##F ::"v"(v), "v"(p) : V3_ALL_CL); break;
     V3_EACH8(V3_C)
 #undef V3_C
   }
@@ -63,14 +66,14 @@ __device__ __forceinline__ void mfma_o(int f, const bf16x8& v, const bf16x8& p) 
 // scores (architectural registers: they feed the VALU) = / += K fragment · Q fragment i
 __device__ __forceinline__ void mfma_s0(f32x16& c, const bf16x8& k, int i) {
   switch (i) {
-#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", 0" : "=&v"(c) : "v"(k)); break;
+#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", 0" : "=&v"(c) : "v"(k) : V3_ALL_CL); break;
     V3_EACH16(V3_C)
 #undef V3_C
   }
 }
 __device__ __forceinline__ void mfma_s(f32x16& c, const bf16x8& k, int i) {
   switch (i) {
-#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", %0" : "+v"(c) : "v"(k)); break;
+#define V3_C(I) case I: asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, " V3_QREG_##I ", %0" : "+v"(c) : "v"(k) : V3_ALL_CL); break;
     V3_EACH16(V3_C)
 #undef V3_C
   }
@@ -78,14 +81,14 @@ __device__ __forceinline__ void mfma_s(f32x16& c, const bf16x8& k, int i) {
 __device__ __forceinline__ void q_write(int i, const bf16x8& q) {
   const u32x4 w = __builtin_bit_cast(u32x4, q);
   switch (i) {
-#define V3_C(I) case I: asm volatile(V3_QWRITE_##I ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : V3_QCL_##I); break;
+#define V3_C(I) case I: asm volatile(V3_QWRITE_##I ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : V3_ALL_CL); break;
     V3_EACH16(V3_C)
 #undef V3_C
   }
 }
 __device__ __forceinline__ void o_zero(int f) {
   switch (f) {
-#define V3_C(F) case F: asm volatile(V3_OZERO_##F ::: V3_OCL_##F); break;
+#define V3_C(F) case F: asm volatile(V3_OZERO_##F ::: V3_ALL_CL); break;
     V3_EACH8(V3_C)
 #undef V3_C
   }
@@ -93,7 +96,7 @@ __device__ __forceinline__ void o_zero(int f) {
 __device__ __forceinline__ void o_scale(int f, float alpha) {
   float tmp;
   switch (f) {
-#define V3_C(F) case F: asm volatile(V3_OSCALE_##F : "=&v"(tmp) : "v"(alpha) : V3_OCL_##F); break;
+#define V3_C(F) case F: asm volatile(V3_OSCALE_##F : "=&v"(tmp) : "v"(alpha) : V3_ALL_CL); break;
     V3_EACH8(V3_C)
 #undef V3_C
   }
@@ -101,7 +104,7 @@ __device__ __forceinline__ void o_scale(int f, float alpha) {
 __device__ __forceinline__ f32x16 o_read(int f) {
   float x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
   switch (f) {
-#define V3_C(F) case F: asm volatile(V3_OREAD_##F : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=v"(x8), "=v"(x9), "=v"(x10), "=v"(x11), "=v"(x12), "=v"(x13), "=v"(x14), "=v"(x15)); break;
+#define V3_C(F) case F: asm volatile(V3_OREAD_##F : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=v"(x8), "=v"(x9), "=v"(x10), "=v"(x11), "=v"(x12), "=v"(x13), "=v"(x14), "=v"(x15) : : V3_ALL_CL); break;
     V3_EACH8(V3_C)
 #undef V3_C
   }
@@ -117,14 +120,41 @@ __device__ __forceinline__ s16x4 tr_read(lds_cptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+constexpr int REC3_WAVE_B = 8 * 16 * 64 * 4 + 64 * 16;   // one wave's partial: 8 O fragments (16 registers x 64 lanes, fp32) + (mA, lA, mB, lB) per lane
+constexpr int REC3_B = 4 * REC3_WAVE_B;                 // 135 168 B per (workgroup, segment)
+constexpr int CNT_ALIGN = 256;
+constexpr int SPLIT_MIN_TILES = 8;
+
 struct V3Geom {
   int S, H, nqb, ntiles, NI;   // NI = H * nqb work items per batch entry
   int spx;                     // workgroups per XCD group (one per CU)
+  int split;                   // key-split tail enabled (workspace present)
 };
+// How the items of one XCD group are cut (identical on host and device): `nfull` items run whole, one per workgroup and round;
+// the key tiles of the `rem` items of the last, partly filled round are dealt to all `spx` workgroups in equal contiguous runs
+// (csrc/attention.hip: the same scheme at 256-row items).
+struct V3Cut { int start, cnt, nfull, rem; };
+__host__ __device__ inline V3Cut v3_cut(const V3Geom& G, int xcd) {
+  V3Cut c;
+  const int base = G.NI >> 3, extra = G.NI & 7;
+  c.cnt = base + (xcd < extra ? 1 : 0);
+  c.start = xcd * base + (xcd < extra ? xcd : extra);
+  c.nfull = c.cnt;
+  c.rem = 0;
+  if (G.split) {
+    const int nf = (c.cnt / G.spx) * G.spx, rem = c.cnt - nf;
+    if (rem > 0 && rem * 16 < G.spx * 15 && (int64_t)rem * G.ntiles >= (int64_t)G.spx * SPLIT_MIN_TILES) {
+      c.nfull = nf;
+      c.rem = rem;
+    }
+  }
+  return c;
+}
 
 __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                      const bf16_t* __restrict__ V, bf16_t* O, int64_t ld, int64_t stride_b,
-                                                                     int64_t ldo, int64_t stride_ob, float scale_log2, const V3Geom G) {
+                                                                     int64_t ldo, int64_t stride_ob, float scale_log2, const V3Geom G,
+                                                                     int* counters, char* records) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][K|V]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -132,10 +162,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
   const int l31 = lane & 31, hh = lane >> 5;
   const int ntiles = G.ntiles;
   const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, b = (int)blockIdx.y;
-  // items of this XCD group: a contiguous run (whole heads stay in one XCD's L2)
-  const int base = G.NI >> 3, extra = G.NI & 7;
-  const int cnt = base + (xcd < extra ? 1 : 0);
-  const int start = xcd * base + (xcd < extra ? xcd : extra);
+  const V3Cut cut = v3_cut(G, xcd);
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
 
   // ---- per-lane constants
@@ -146,42 +173,64 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     const int row_t = (wave * 4 + p) * 4 + srow;
     soff[p] = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
   }
-  int kp[8];                                             // K row read: row 32kb + l31, chunk 2ks + hh
+  int kp[8];                                             // K row read: row 32kb + l31, chunk 2ks + hh (LDS byte address in stage 0)
   {
     const int ksw = swz(l31);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) kp[ks] = (int)lds0 + l31 * 256 + (((2 * ks + hh) ^ ksw) << 4);
   }
   const int tq = (lane >> 2) & 3, tp = lane & 3, tg1 = (lane >> 4) & 1;
-  int vp[2][4];                                          // Vᵀ transposed reads (see attention.hip)
+  int vp[8];                                             // Vᵀ transposed reads (see attention.hip): [row block 0/1][dt]
   {
     const int cl = tg1 * 2 + (tp >> 1);
     const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      vp[0][dt] = (int)lds0 + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
-      vp[1][dt] = (int)lds0 + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
+      vp[dt] = (int)lds0 + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
+      vp[4 + dt] = (int)lds0 + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
     }
   }
   const int tile_stride_b = BKV * (int)ld * 2;
 
-  for (int it = slot; it < cnt; it += G.spx) {
-    const int item = start + it;
+  // ---- this workgroup's segments: its whole items (one per round), then the one or two pieces of its run of the split items
+  const int nwhole = slot < cut.nfull ? (cut.nfull - slot + G.spx - 1) / G.spx : 0;
+  int run_lo = 0, run_hi = 0, run_i0 = 0;
+  if (cut.rem && slot < G.spx) {
+    const unsigned U = (unsigned)cut.rem * (unsigned)ntiles;
+    run_lo = (int)((unsigned)slot * U / (unsigned)G.spx);
+    run_hi = (int)((unsigned)(slot + 1) * U / (unsigned)G.spx);
+    run_i0 = run_lo / ntiles;
+  }
+  const int nseg = nwhole + (cut.rem && slot < G.spx ? 2 : 0);
+
+  for (int si = 0; si < nseg; ++si) {
+    int item, tb, te, seg = 0;
+    if (si < nwhole) {
+      item = cut.start + slot + si * G.spx;
+      tb = 0;
+      te = ntiles;
+    } else {
+      seg = si - nwhole;
+      item = cut.start + cut.nfull + run_i0 + seg;
+      tb = seg == 0 ? run_lo - run_i0 * ntiles : 0;
+      te = seg == 0 ? min(run_hi - run_i0 * ntiles, ntiles) : run_hi - (run_i0 + 1) * ntiles;
+      if (te <= tb) continue;
+    }
     const int head = item / G.nqb;
     const int q0 = (item - head * G.nqb) * BQ3;
     const bf16_t* Qb = Q + b * stride_b + head * DH;
     const rt_srd_t rsrcK = rt_make_srd(K + b * stride_b + head * DH), rsrcV = rt_make_srd(V + b * stride_b + head * DH);
-    auto dma_piece = [&](int st, int tix, int i) {      // piece i of 8: K pieces 0..3, V pieces 4..7 of this wave
+    auto dma_piece = [&](int st, int tix, int i) __attribute__((always_inline)) {   // piece i of 8: K pieces 0..3, V pieces 4..7 of this wave
       const uint32_t dst = lds0 + st * STAGE_B + ((i & 4) ? TILE_B : 0) + (wave * 4 + (i & 3)) * 1024;
       rt_dma16_asm((i & 4) ? rsrcV : rsrcK, dst, soff[i & 3], (uint32_t)(tix * tile_stride_b));
     };
 
-    __syncthreads();                                     // the previous item's LDS reads are done
+    __syncthreads();                                     // the previous segment's LDS reads (tiles, ticket word) are done
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(0, 0, i);
-    if (ntiles > 1) {
+    for (int i = 0; i < 8; ++i) dma_piece(0, tb, i);
+    if (tb + 1 < te) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma_piece(1, 1, i);
+      for (int i = 0; i < 8; ++i) dma_piece(1, tb + 1, i);
     }
     // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7] for its row of block a and of block b
     {
@@ -193,7 +242,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         qb[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ld + ks * 16);
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { q_write(ks, qa[ks]); q_write(8 + ks, qb[ks]); }     // parked in a[128:191] for the whole item
+      for (int ks = 0; ks < 8; ++ks) { q_write(ks, qa[ks]); q_write(8 + ks, qb[ks]); }     // parked in a[128:191] for the whole segment
 #pragma unroll
       for (int f = 0; f < 8; ++f) o_zero(f);
       asm volatile("s_nop 7" ::: "memory");               // accvgpr writes settle before the first MFMA reads them
@@ -205,27 +254,33 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     bf16x8 kf[8], vf[8];                // K fragments of one 32-key half [ks]; Vᵀ fragments of one half [s2*4 + dt]
     float lsnapA = 0.f, lsnapB = 0.f;   // row sums before a half's speculative numerators were added
     float mxa0, mxa1, mxb0, mxb1;       // running-max chains
+    float pp[2];                        // exp2 results waiting for their add / pack (one gap later: no trans->VALU stall)
+    int pend = -1;                      // the softmax element whose second stage is pending (a compile-time constant after unrolling)
 
-    // one softmax element o of a half (order: k-step, query block, j): numerator against the CURRENT running max
-    // The opaque uses pin every step where it is written: left alone, LLVM sinks the speculative numerators of a half below
-    // the decision branch that may redo them (they are only NEEDED after it) — all 16 in one lump, with no MFMA beside them.
-    auto elem = [&](int o, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+    // One softmax element o of a half (order: k-step, query block, j), against the CURRENT running max, in two stages a gap apart:
+    // A = fma + exp2, B = row-sum add + bf16 pack. The opaque uses pin every step where it is written: left alone, LLVM sinks the
+    // speculative numerators of a half below the decision branch that may redo them — all 16 in one lump, no MFMA beside them.
+    auto elem_a = [&](int o, const f32x16& Sa, const f32x16& Sb) __attribute__((always_inline)) {
       const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7, r = 8 * ks + j;
-      if (qb) {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(Sb[r], scale_log2, -mB));
-        asm volatile("" : "+v"(p));
-        lB += p;
-        asm volatile("" : "+v"(lB));
-        P[1][ks][j] = (__bf16)p;
-        if (j & 1) asm volatile("" : "+v"(P[1][ks]));
-      } else {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(Sa[r], scale_log2, -mA));
-        asm volatile("" : "+v"(p));
-        lA += p;
-        asm volatile("" : "+v"(lA));
-        P[0][ks][j] = (__bf16)p;
-        if (j & 1) asm volatile("" : "+v"(P[0][ks]));
-      }
+      float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA));
+      asm volatile("" : "+v"(p));
+      pp[o & 1] = p;
+    };
+    auto elem_b = [&](int o, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7;
+      const float p = pp[o & 1];
+      if (qb) { lB += p; asm volatile("" : "+v"(lB)); } else { lA += p; asm volatile("" : "+v"(lA)); }
+      P[qb][ks][j] = (__bf16)p;
+      if (j & 1) asm volatile("" : "+v"(P[qb][ks]));
+    };
+    auto elem = [&](int o, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      if (pend >= 0) elem_b(pend, P);
+      elem_a(o, Sa, Sb);
+      pend = o;
+    };
+    auto elem_flush = [&](bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      if (pend >= 0) elem_b(pend, P);
+      pend = -1;
     };
     // step k (0..7) of the max chain over the 16 scores of one fragment
     auto maxstep = [&](int k, const f32x16& s, float& m0, float& m1) __attribute__((always_inline)) {
@@ -256,14 +311,14 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
 #pragma unroll
         for (int f = 0; f < 8; ++f) o_scale(f, (f & 1) ? alB : alA);
 #pragma unroll
-        for (int o = 0; o < 16; ++o) elem(o, Sa, Sb, P);
+        for (int o = 0; o < 16; ++o) { elem_a(o, Sa, Sb); elem_b(o, P); }
       }
     };
     // LDS read addresses of the stage in use: ka = K rows of one stage, va = Vᵀ blocks of one stage. They are moved to the next
     // stage once per tile (16 integer adds, as fillers) and made opaque, so every read is base register + immediate.
     int ka[8], va[8];
-    auto set_ka = [&](int i, int sbase) __attribute__((always_inline)) { ka[i] = kp[i] + sbase; asm volatile("" : "+v"(ka[i])); };
-    auto set_va = [&](int i, int sbase) __attribute__((always_inline)) { va[i] = vp[i >> 2][i & 3] + sbase; asm volatile("" : "+v"(va[i])); };
+    auto set_ka = [&](int i, int sbase) __attribute__((always_inline)) { int x = kp[i]; asm volatile("" : "+v"(x)); ka[i] = x + sbase; asm volatile("" : "+v"(ka[i])); };
+    auto set_va = [&](int i, int sbase) __attribute__((always_inline)) { int x = vp[i]; asm volatile("" : "+v"(x)); va[i] = x + sbase; asm volatile("" : "+v"(va[i])); };
     auto kread = [&](int kb, int ks) __attribute__((always_inline)) -> bf16x8 {
       return *(const __attribute__((address_space(3))) bf16x8*)((lds_cptr)(uintptr_t)(uint32_t)(ka[ks] + kb * 8192));
     };
@@ -295,24 +350,41 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         V3_SB();
       }
     };
+    // fillers of a group that finishes a half: max exchange (gaps 0, 1), decision (gap 2), numerators 16..31 (gaps 3..15)
+    auto second_half = [&](int g, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2], float ra, float rb, float& ea, float& eb)
+        __attribute__((always_inline)) {
+      if (g == 0) ea = exchange(ra);
+      if (g == 1) eb = exchange(rb);
+      if (g == 2) decide(ea, eb, Sa, Sb, P);
+      if (g >= 3 && g <= 12) elem(13 + g, Sa, Sb, P);                                  // 16..25
+      if (g >= 13) { elem(26 + 2 * (g - 13), Sa, Sb, P); elem(27 + 2 * (g - 13), Sa, Sb, P); }   // 26..31
+      if (g == 15) elem_flush(P);
+    };
+    // fillers of a PV group that starts the next half: speculative numerators 0..15, its max chains
+    auto first_half = [&](int g, f32x16& Sa, f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+      if (g == 0) V3_PIN(Sa);                      // two MFMAs behind its last accumulation: safe to read from here on
+      if (g == 1) V3_PIN(Sb);
+      if (g >= 1) elem(g - 1, Sa, Sb, P);          // elements 0..14
+      if (g == 15) { elem(15, Sa, Sb, P); elem_flush(P); }
+      if (g >= 1 && g < 9) maxstep(g - 1, Sa, mxa0, mxa1);
+      if (g >= 8) maxstep(g - 8, Sb, mxb0, mxb1);
+    };
 
     // ---------------------------------------------------------------------------------------------- the tile loop
-    // stage of tile t = t % 3; tiles 0 and 1 are in flight (the waits of the Q loads above already covered them: in-order counter)
+    // stage of tile t = (t - tb) % 3; the segment's first two tiles are in flight (the waits of the Q loads covered them: in-order counter)
     float rka = 0.f, rkb = 0.f;        // row maxima (this lane's 16 keys) of the half whose decision is pending
     auto tile = [&](auto first_c, auto last_c, int t) __attribute__((always_inline)) {
       constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
-      const int sb = (t % NSTAGE) * STAGE_B;
-      const int sbn = ((t + 1) % NSTAGE) * STAGE_B;
-      const int stp = (t + 2) % NSTAGE;                            // stage of tile t-1 (= of tile t+2)
-      const bool more2 = t + 2 < ntiles;
+      const int rel = t - tb;
+      const int sb = (rel % NSTAGE) * STAGE_B;
+      const int sbn = ((rel + 1) % NSTAGE) * STAGE_B;
+      const int stp = (rel + 2) % NSTAGE;                          // stage of tile t-1 (= of tile t+2)
+      const bool more2 = t + 2 < te;
       float ea = 0.f, eb = 0.f;
       // ---- G1: Sᵀ(k0,t) ∥ decision + numerators 16..31 of k1(t-1), Vᵀ(k1,t-1) fragments
       qk_group(sAa, sAb, [&](int g) __attribute__((always_inline)) {
         if constexpr (!first) {
-          if (g == 0) ea = exchange(rka);
-          if (g == 1) { eb = exchange(rkb); decide(ea, eb, sBa, sBb, pB); }
-          if (g >= 2) elem(14 + g, sBa, sBb, pB);
-          if (g == 2 || g == 3) elem(g == 2 ? 30 : 31, sBa, sBb, pB);
+          second_half(g, sBa, sBb, pB, rka, rkb, ea, eb);
           if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(1, i >> 2, i & 3); }
         }
       });
@@ -320,12 +392,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       lsnapA = lA; lsnapB = lB;
       if constexpr (!first) {
         pv_group(pB, [&](int g) __attribute__((always_inline)) {
-          if (g == 0) V3_PIN(sAa);                    // two MFMAs behind its last accumulation (G1 g = 14): safe to read from here on
-          if (g == 1) V3_PIN(sAb);
-          if (g >= 1) elem(g - 1, sAa, sAb, pA);      // elements 0..14; element 15 below
-          if (g == 15) elem(15, sAa, sAb, pA);
-          if (g >= 1 && g < 9) maxstep(g - 1, sAa, mxa0, mxa1);
-          if (g >= 8) maxstep(g - 8, sAb, mxb0, mxb1);
+          first_half(g, sAa, sAb, pA);
           if (g & 1) kf[g >> 1] = kread(1, g >> 1); else set_va(g >> 1, sb);
         });
       } else {
@@ -341,19 +408,14 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       V3_SB();
       // ---- G3: Sᵀ(k1,t) ∥ exchange + decision for k0(t), numerators 16..31 (first tile: all 32) of k0(t), Vᵀ(k0,t) fragments
       qk_group(sBa, sBb, [&](int g) __attribute__((always_inline)) {
-        if (g == 0) ea = exchange(rka);
-        if (g == 1) {
-          eb = exchange(rkb);
-          if constexpr (first) { mA = fmaxf(mA, ea); mB = fmaxf(mB, eb); }      // nothing accumulated yet: just fix the maxima
-          else decide(ea, eb, sAa, sAb, pA);
-        }
         if constexpr (first) {
+          if (g == 0) ea = exchange(rka);
+          if (g == 1) { eb = exchange(rkb); mA = fmaxf(mA, ea); mB = fmaxf(mB, eb); }      // nothing accumulated yet: just fix the maxima
           if (g >= 2) { elem(2 * (g - 2), sAa, sAb, pA); elem(2 * (g - 2) + 1, sAa, sAb, pA); }
           if (g == 14) { elem(28, sAa, sAb, pA); elem(29, sAa, sAb, pA); }
-          if (g == 15) { elem(30, sAa, sAb, pA); elem(31, sAa, sAb, pA); }
+          if (g == 15) { elem(30, sAa, sAb, pA); elem(31, sAa, sAb, pA); elem_flush(pA); }
         } else {
-          if (g >= 2) elem(14 + g, sAa, sAb, pA);
-          if (g == 2 || g == 3) elem(g == 2 ? 30 : 31, sAa, sAb, pA);
+          second_half(g, sAa, sAb, pA, rka, rkb, ea, eb);
         }
         if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(0, i >> 2, i & 3); } else { set_ka(g >> 1, sbn); }
       });
@@ -366,12 +428,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       // ---- G4: PV(k0,t) ∥ speculative numerators 0..15 of k1(t), max chains of k1(t), K(k0,t+1) fragments, DMA of tile t+2
       lsnapA = lA; lsnapB = lB;
       pv_group(pA, [&](int g) __attribute__((always_inline)) {
-        if (g == 0) V3_PIN(sBa);
-        if (g == 1) V3_PIN(sBb);
-        if (g >= 1) elem(g - 1, sBa, sBb, pB);
-        if (g == 15) elem(15, sBa, sBb, pB);
-        if (g >= 1 && g < 9) maxstep(g - 1, sBa, mxa0, mxa1);
-        if (g >= 8) maxstep(g - 8, sBb, mxb0, mxb1);
+        first_half(g, sBa, sBb, pB);
         if constexpr (!last) {
           if (g & 1) kf[g >> 1] = kread(0, g >> 1);
           if ((g & 1) == 0 && more2) dma_piece(stp, t + 2, g >> 1);
@@ -385,6 +442,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         decide(ea2, eb2, sBa, sBb, pB);
 #pragma unroll
         for (int o = 16; o < 32; ++o) elem(o, sBa, sBb, pB);
+        elem_flush(pB);
 #pragma unroll
         for (int i = 0; i < 8; ++i) vf[(i >> 2) * 4 + (i & 3)] = vread(1, i >> 2, i & 3);
         V3_SB();
@@ -393,44 +451,124 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     };
     using TT = std::true_type;
     using FF = std::false_type;
-    __syncthreads();                                     // tile 0 has landed everywhere (every wave's Q-load waits covered its DMA)
+    __syncthreads();                                     // the segment's first tile has landed everywhere (every wave's Q-load waits covered its DMA)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { set_ka(ks, 0); kf[ks] = kread(0, ks); }
-    tile(TT{}, FF{}, 0);
-    for (int t = 1; t + 1 < ntiles; ++t) tile(FF{}, FF{}, t);
-    tile(FF{}, TT{}, ntiles - 1);
+    if (te - tb == 1) {
+      tile(TT{}, TT{}, tb);
+    } else {
+      tile(TT{}, FF{}, tb);
+      for (int t = tb + 1; t + 1 < te; ++t) tile(FF{}, FF{}, t);
+      tile(FF{}, TT{}, te - 1);
+    }
 
-    // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
+    // ---- the segment's result: Oᵀ in a[0:127] (unnormalised), (m, l) per query block
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMA has retired before its accumulators are read
+    const bool whole = (tb == 0 && te == ntiles);
+    f32x16 oc[8];                                                  // [d block * 2 + query block]
+    if (whole) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) oc[f] = o_read(f);
+    } else {
+      // ---- partial: write (Oᵀ, m, l) through to memory, take a ticket on the item; the last ticket combines the item's records
+      const int jpart = slot;
+      const int ritem = item - (cut.start + cut.nfull);            // index among the split items of this group
+      char* rec = records + ((((int64_t)b * 8 + xcd) * G.spx + jpart) * 2 + seg) * (int64_t)REC3_B + wave * REC3_WAVE_B;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, REC3_WAVE_B, 0x00020000);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const f32x16 x = o_read(f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 vv = {x[4 * g + 0], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rs, (f * 4 + g) * 1024 + lane * 16, 0, 16 /* sc1: write-through */);
+        }
+      }
+      {
+        const f32x4 ml = {mA, lA, mB, lB};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, 32768 + lane * 16, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+      __syncthreads();
+      int* cnt = counters + (int64_t)b * G.NI + item;
+      const unsigned U = (unsigned)cut.rem * (unsigned)ntiles, spx = (unsigned)G.spx;
+      const unsigned a = (unsigned)ritem * (unsigned)ntiles, bnd = a + (unsigned)ntiles;
+      const int j_first = (int)(((a + 1) * spx + U - 1) / U) - 1;
+      const int j_last = min(G.spx - 1, (int)((bnd * spx + U - 1) / U) - 1);
+      const int nparts = j_last - j_first + 1;
+      volatile int* flag = reinterpret_cast<volatile int*>(smem);
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lastp = (old == nparts - 1) ? 1 : 0;
+        if (lastp) {
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // drop this CU's stale lines
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = lastp;
+      }
+      __syncthreads();
+      const int lastp = __builtin_amdgcn_readfirstlane(*flag);
+      if (!lastp) continue;
+      // record of splitting workgroup j for this item: its second segment when the item starts after the run does
+      auto rec_of = [&](int j) -> const char* {
+        const unsigned lo_j = (unsigned)j * U / spx;
+        const int sj = (a > lo_j) ? 1 : 0;
+        return records + ((((int64_t)b * 8 + xcd) * G.spx + j) * 2 + sj) * (int64_t)REC3_B + wave * REC3_WAVE_B;
+      };
+      // pass 1: common maxima; pass 2: weighted sums IN RUN ORDER (bitwise reproducible whatever the arrival order was)
+      float MA = -INFINITY, MB = -INFINITY;
+      for (int j = j_first; j <= j_last; ++j) {
+        const f32x4 ml = *reinterpret_cast<const f32x4*>(rec_of(__builtin_amdgcn_readfirstlane(j)) + 32768 + lane * 16);
+        MA = fmaxf(MA, ml[0]);
+        MB = fmaxf(MB, ml[2]);
+      }
+      lA = 0.f; lB = 0.f;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oc[f][r] = 0.f;
+      for (int j = j_first; j <= j_last; ++j) {
+        const char* rj = rec_of(__builtin_amdgcn_readfirstlane(j));
+        const f32x4 ml = *reinterpret_cast<const f32x4*>(rj + 32768 + lane * 16);
+        const float wa = __builtin_amdgcn_exp2f(ml[0] - MA), wb = __builtin_amdgcn_exp2f(ml[2] - MB);
+        lA = __builtin_fmaf(ml[1], wa, lA);
+        lB = __builtin_fmaf(ml[3], wb, lB);
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rj + (f * 4 + g) * 1024 + lane * 16);
+            const float w = (f & 1) ? wb : wa;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oc[f][4 * g + e] = __builtin_fmaf(v[e], w, oc[f][4 * g + e]);
+          }
+      }
+    }
+    // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
     const float invA = 1.0f / (lA + __shfl_xor(lA, 32)), invB = 1.0f / (lB + __shfl_xor(lB, 32));
     bf16_t* orow = O + b * stride_ob + (int64_t)(q0 + wave * 64 + l31) * ldo + head * DH;
     {
-      f32x16 oA[4];
+      f32x16 t4[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) oA[dt] = o_read(dt * 2);
-      rt_store_o_rows(orow, true, hh, oA, invA);
-    }
-    {
-      f32x16 oB[4];
+      for (int dt = 0; dt < 4; ++dt) t4[dt] = oc[dt * 2];
+      rt_store_o_rows(orow, true, hh, t4, invA);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) oB[dt] = o_read(dt * 2 + 1);
-      rt_store_o_rows(orow + 32 * ldo, true, hh, oB, invB);
+      for (int dt = 0; dt < 4; ++dt) t4[dt] = oc[dt * 2 + 1];
+      rt_store_o_rows(orow + 32 * ldo, true, hh, t4, invB);
     }
   }
 }
 
 int g_v3_mode = -1;       // 1 = use attention_v3 where it applies (RT_ATTN_V3, default 1)
-
-}  // namespace
-
-// Called by rt_attention_fwd: returns 1 when the launch was taken over, 0 when the shape is left to attention.hip, < 0 / hipError on failure.
-int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
-                        int32_t B, int32_t S, int32_t H, float scale, void* stream) {
+int v3_mode_now() {
   if (g_v3_mode < 0) {
     const char* e = getenv("RT_ATTN_V3");
     g_v3_mode = e ? atoi(e) : 1;
   }
-  if (!g_v3_mode || S % BQ3 != 0 || (ldo % 8) || (stride_ob % 8) || !RT_ALIGNED(o, 16)) return 0;
+  return g_v3_mode;
+}
+V3Geom v3_geom(int S, int H, bool split) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int x = 0;
@@ -439,6 +577,32 @@ int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, in
   V3Geom G;
   G.S = S; G.H = H; G.nqb = S / BQ3; G.ntiles = S / BKV; G.NI = H * G.nqb;
   G.spx = cus / 8 > 0 ? cus / 8 : 1;
+  G.split = split ? 1 : 0;
+  return G;
+}
+
+}  // namespace
+
+// Workspace attention_v3 wants for (B, S, H): ticket counters + partial records of the key-split tail; 0 when nothing would be split
+// or the shape is not taken. rt_attention_ws_bytes (attention.hip) returns the larger of the two kernels' needs.
+int64_t rt_attention_v3_ws_bytes(int32_t B, int32_t S, int32_t H) {
+  if (S % BQ3 != 0) return 0;
+  const V3Geom G = v3_geom(S, H, true);
+  bool any = false;
+  for (int x = 0; x < 8; ++x) any = any || v3_cut(G, x).rem > 0;
+  if (!any) return 0;
+  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
+  return cnt_b + (int64_t)B * 8 * G.spx * 2 * REC3_B;
+}
+
+// Called by rt_attention_fwd: returns 1 when the launch was taken over, 0 when the shape is left to attention.hip, < 0 / hipError on failure.
+int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
+                        int32_t B, int32_t S, int32_t H, float scale, void* ws, int64_t ws_bytes, void* stream) {
+  if (!v3_mode_now() || S % BQ3 != 0 || (ldo % 8) || (stride_ob % 8) || !RT_ALIGNED(o, 16)) return 0;
+  const int64_t need = rt_attention_v3_ws_bytes(B, S, H);
+  const bool split = ws != nullptr && need > 0 && ws_bytes >= need && RT_ALIGNED(ws, 256);
+  const V3Geom G = v3_geom(S, H, split);
+  if ((int64_t)G.NI * (G.ntiles + 1) * G.spx >= ((int64_t)1 << 31)) return 0;
   const int lds = NSTAGE * STAGE_B;
   static bool attr_done = false;
   if (!attr_done) {
@@ -446,20 +610,22 @@ int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, in
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int per = (G.NI + 7) / 8;
-  const int slots = per < G.spx ? per : G.spx;
+  int slots = 0;
+  for (int x = 0; x < 8; ++x) {
+    const V3Cut c = v3_cut(G, x);
+    const int s = c.rem ? G.spx : (c.nfull < G.spx ? c.nfull : G.spx);
+    slots = s > slots ? s : slots;
+  }
+  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
   hipLaunchKernelGGL(attention_v3_kernel, dim3(8 * slots, B), dim3(V3_THREADS), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
-                     (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, scale * 1.4426950408889634f, G);
+                     (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, scale * 1.4426950408889634f, G, split ? (int*)ws : nullptr,
+                     split ? (char*)ws + cnt_b : nullptr);
   const int st = rt_hip_status();
   return st == RT_OK ? 1 : st;
 }
 
 int rt_attention_v3_mode(int mode) {
-  if (g_v3_mode < 0) {
-    const char* e = getenv("RT_ATTN_V3");
-    g_v3_mode = e ? atoi(e) : 1;
-  }
-  const int prev = g_v3_mode;
+  const int prev = v3_mode_now();
   if (mode >= 0) g_v3_mode = mode;
   return prev;
 }

@@ -101,3 +101,17 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/librt_reptext_hip.so")
     with pytest.raises(native.NativeLibraryMissing):
         native.load()
+
+
+def test_attention_v3_code_object_keeps_out_of_the_asm_owned_registers():
+    """csrc/attention_v3.hip names the accumulator registers a0..a191 literally (O and Q live there for a whole work item). The
+    compiler must not have put anything of its own in them: no VGPR spill, no scratch, no compiler-generated v_accvgpr_* that
+    names a0..a191 (tools/audit_v3_asm.py over the -S output of the same flags the Makefile builds with)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "audit_v3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK " in r.stdout
