@@ -25,11 +25,10 @@
 //     in front of G4(t) publishes tile t+1 (copied a whole tile earlier) and frees the stage of tile t-1 for tile t+2.
 //
 // Applies when S is a multiple of 256 (every shape of the pipelines at 1024² / 1536² / 256²); other shapes run attention.hip.
-// OPT-IN (rt_attention_variant(1) / RT_ATTN_V3=1): measured on MI355X it is 2-3 % faster than attention.hip where the items fill
-// whole rounds (S = 4096 x 32 heads: 250 vs 257 us) and 7-9 % SLOWER at the model's S = 4608 x 24 heads, where 54 items per XCD
-// meet 32 workgroups: with one workgroup per CU nothing overlaps a segment's prologue, partial-record write and combine, which the
-// two co-resident workgroups of attention.hip hide for each other. DESIGN.md §5 has the ablation table (MFMA-only floor of this
-// structure: 183 us = the chip holding 1.6 GHz under back-to-back MFMAs).
+// Default for S >= 1536 (rt_attention_variant / RT_ATTN_V3 = 0 turns it off, 2 forces it wherever S % 256 == 0). Measured on MI355X
+// against attention.hip, interleaved in one process: S = 4608 x 24 heads 247 vs 264 us (-6.6 %), 4096 x 32 heads 244 vs 265,
+// batch 4 -5 %, S = 9728 986 vs 1065 us (1179 TFLOP/s); S = 768 25 vs 19 us (left to attention.hip). DESIGN.md §5 has the
+// ablation table (MFMA-only floor of this structure at S = 4096 x 32: 183 us = the chip holding ~1.6 GHz under back-to-back MFMAs).
 #include "rt_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -481,18 +480,26 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
       tile(FF{}, TT{}, te - 1);
     }
 
-    // ---- the segment's result: Oᵀ in a[0:127] (unnormalised), (m, l) per query block
+    // ---- the segment's result: Oᵀ in a[0:127] (unnormalised), row sums in a[192:223], maxima in (mA, mB)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMA has retired before its accumulators are read
     const bool whole = (tb == 0 && te == ntiles);
-    f32x16 oc[8];                                                  // [d block * 2 + query block]
-    float lA = o_read(8)[0], lB = o_read(9)[0];                    // row sums: every register of an L fragment holds its query's sum
+    const float lA = o_read(8)[0], lB = o_read(9)[0];              // every register of an L fragment holds its query's row sum
+    bf16_t* orow = O + b * stride_ob + (int64_t)(q0 + wave * 64 + l31) * ldo + head * DH;
     if (whole) {
+      // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
 #pragma unroll
-      for (int f = 0; f < 8; ++f) oc[f] = o_read(f);
-    } else {
-      // ---- partial: write (Oᵀ, m, l) through to memory, take a ticket on the item; the last ticket combines the item's records
-      const int jpart = slot;
-      const int ritem = item - (cut.start + cut.nfull);            // index among the split items of this group
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 t4[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) t4[dt] = o_read(dt * 2 + qb);
+        rt_store_o_rows(orow + qb * 32 * ldo, true, hh, t4, 1.0f / (qb ? lB : lA));
+      }
+      continue;
+    }
+    // ---- partial: write (Oᵀ, m, l) through to memory, take a ticket on the item; the last ticket combines the item's records
+    const int jpart = slot;
+    const int ritem = item - (cut.start + cut.nfull);            // index among the split items of this group
+    {
       char* rec = records + ((((int64_t)b * 8 + xcd) * G.spx + jpart) * 2 + seg) * (int64_t)REC3_B + wave * REC3_WAVE_B;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, REC3_WAVE_B, 0x00020000);
 #pragma unroll
@@ -504,87 +511,80 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rs, (f * 4 + g) * 1024 + lane * 16, 0, 16 /* sc1: write-through */);
         }
       }
-      {
-        const f32x4 ml = {mA, lA, mB, lB};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, 32768 + lane * 16, 0, 16);
+      const f32x4 ml = {mA, lA, mB, lB};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, 32768 + lane * 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its write-through stores
+    __syncthreads();
+    int* cnt = counters + (int64_t)b * G.NI + item;
+    const unsigned U = (unsigned)cut.rem * (unsigned)ntiles, spx = (unsigned)G.spx;
+    const unsigned a = (unsigned)ritem * (unsigned)ntiles, bnd = a + (unsigned)ntiles;
+    const int j_first = (int)(((a + 1) * spx + U - 1) / U) - 1;
+    const int j_last = min(G.spx - 1, (int)((bnd * spx + U - 1) / U) - 1);
+    const int nparts = j_last - j_first + 1;
+    volatile int* flag = reinterpret_cast<volatile int*>(smem);
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int lastp = (old == nparts - 1) ? 1 : 0;
+      if (lastp) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // drop this CU's stale lines
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
-      __syncthreads();
-      int* cnt = counters + (int64_t)b * G.NI + item;
-      const unsigned U = (unsigned)cut.rem * (unsigned)ntiles, spx = (unsigned)G.spx;
-      const unsigned a = (unsigned)ritem * (unsigned)ntiles, bnd = a + (unsigned)ntiles;
-      const int j_first = (int)(((a + 1) * spx + U - 1) / U) - 1;
-      const int j_last = min(G.spx - 1, (int)((bnd * spx + U - 1) / U) - 1);
-      const int nparts = j_last - j_first + 1;
-      volatile int* flag = reinterpret_cast<volatile int*>(smem);
-      if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int lastp = (old == nparts - 1) ? 1 : 0;
-        if (lastp) {
-          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // drop this CU's stale lines
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = lastp;
-      }
-      __syncthreads();
-      const int lastp = __builtin_amdgcn_readfirstlane(*flag);
-      if (!lastp) continue;
-      // record of splitting workgroup j for this item: its second segment when the item starts after the run does
-      auto rec_of = [&](int j) -> const char* {
-        const unsigned lo_j = (unsigned)j * U / spx;
-        const int sj = (a > lo_j) ? 1 : 0;
-        return records + ((((int64_t)b * 8 + xcd) * G.spx + j) * 2 + sj) * (int64_t)REC3_B + wave * REC3_WAVE_B;
-      };
-      // pass 1: common maxima; pass 2: weighted sums IN RUN ORDER (bitwise reproducible whatever the arrival order was)
-      float MA = -INFINITY, MB = -INFINITY;
-      for (int j = j_first; j <= j_last; ++j) {
-        const f32x4 ml = *reinterpret_cast<const f32x4*>(rec_of(__builtin_amdgcn_readfirstlane(j)) + 32768 + lane * 16);
-        MA = fmaxf(MA, ml[0]);
-        MB = fmaxf(MB, ml[2]);
-      }
-      lA = 0.f; lB = 0.f;
+      *flag = lastp;
+    }
+    __syncthreads();
+    if (!__builtin_amdgcn_readfirstlane(*flag)) continue;
+    // record of splitting workgroup j for this item: its second segment when the item starts after the run does
+    auto rec_of = [&](int j) -> const char* {
+      const unsigned lo_j = (unsigned)j * U / spx;
+      const int sj = (a > lo_j) ? 1 : 0;
+      return records + ((((int64_t)b * 8 + xcd) * G.spx + j) * 2 + sj) * (int64_t)REC3_B + wave * REC3_WAVE_B;
+    };
+    // pass 1: common maxima and the combined row sums; pass 2: per query block, weighted sums of the records IN RUN ORDER
+    // (bitwise reproducible whatever the arrival order was). One query block's four fragments at a time: 64 accumulators.
+    float MA = -INFINITY, MB = -INFINITY;
+    for (int j = j_first; j <= j_last; ++j) {
+      const f32x4 ml = *reinterpret_cast<const f32x4*>(rec_of(__builtin_amdgcn_readfirstlane(j)) + 32768 + lane * 16);
+      MA = fmaxf(MA, ml[0]);
+      MB = fmaxf(MB, ml[2]);
+    }
+    float LA = 0.f, LB = 0.f;
+    for (int j = j_first; j <= j_last; ++j) {
+      const f32x4 ml = *reinterpret_cast<const f32x4*>(rec_of(__builtin_amdgcn_readfirstlane(j)) + 32768 + lane * 16);
+      LA = __builtin_fmaf(ml[1], __builtin_amdgcn_exp2f(ml[0] - MA), LA);
+      LB = __builtin_fmaf(ml[3], __builtin_amdgcn_exp2f(ml[2] - MB), LB);
+    }
 #pragma unroll
-      for (int f = 0; f < 8; ++f)
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 t4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oc[f][r] = 0.f;
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t4[dt][r] = 0.f;
       for (int j = j_first; j <= j_last; ++j) {
         const char* rj = rec_of(__builtin_amdgcn_readfirstlane(j));
         const f32x4 ml = *reinterpret_cast<const f32x4*>(rj + 32768 + lane * 16);
-        const float wa = __builtin_amdgcn_exp2f(ml[0] - MA), wb = __builtin_amdgcn_exp2f(ml[2] - MB);
-        lA = __builtin_fmaf(ml[1], wa, lA);
-        lB = __builtin_fmaf(ml[3], wb, lB);
+        const float w = __builtin_amdgcn_exp2f(qb ? ml[2] - MB : ml[0] - MA);
 #pragma unroll
-        for (int f = 0; f < 8; ++f)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rj + (f * 4 + g) * 1024 + lane * 16);
-            const float w = (f & 1) ? wb : wa;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rj + ((dt * 2 + qb) * 4 + g) * 1024 + lane * 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) oc[f][4 * g + e] = __builtin_fmaf(v[e], w, oc[f][4 * g + e]);
+            for (int e = 0; e < 4; ++e) t4[dt][4 * g + e] = __builtin_fmaf(v[e], w, t4[dt][4 * g + e]);
           }
       }
-    }
-    // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31 of each block, d = 32dt + (r&3) + 8(r>>2) + 4hh
-    const float invA = 1.0f / lA, invB = 1.0f / lB;
-    bf16_t* orow = O + b * stride_ob + (int64_t)(q0 + wave * 64 + l31) * ldo + head * DH;
-    {
-      f32x16 t4[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) t4[dt] = oc[dt * 2];
-      rt_store_o_rows(orow, true, hh, t4, invA);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) t4[dt] = oc[dt * 2 + 1];
-      rt_store_o_rows(orow + 32 * ldo, true, hh, t4, invB);
+      rt_store_o_rows(orow + qb * 32 * ldo, true, hh, t4, 1.0f / (qb ? LB : LA));
     }
   }
 }
 
-int g_v3_mode = -1;       // 1 = use attention_v3 where it applies (RT_ATTN_V3; default 0: see DESIGN.md §5 for the measurements)
+int g_v3_mode = -1;       // 1 (default, RT_ATTN_V3) = use attention_v3 where it applies and pays; 2 = wherever it applies (tests)
 int v3_mode_now() {
   if (g_v3_mode < 0) {
     const char* e = getenv("RT_ATTN_V3");
-    g_v3_mode = e ? atoi(e) : 0;
+    g_v3_mode = e ? atoi(e) : 1;
   }
   return g_v3_mode;
 }
@@ -623,6 +623,9 @@ int64_t rt_attention_v3_ws_bytes(int32_t B, int32_t S, int32_t H) {
 int rt_attention_v3_try(const void* q, const void* k, const void* v, void* o, int64_t ld, int64_t stride_b, int64_t ldo, int64_t stride_ob,
                         int32_t B, int32_t S, int32_t H, float scale, void* ws, int64_t ws_bytes, void* stream) {
   if (!v3_mode_now() || S % BQ3 != 0 || (ldo % 8) || (stride_ob % 8) || !RT_ALIGNED(o, 16)) return 0;
+  // short sequences (config 1's S = 768: 25 vs 19 us) stay with attention.hip, whose two workgroups per CU hide each other's
+  // prologues; from ~1.5 k keys on the 64-rows-per-wave loop wins (S = 4608: 247 vs 264 us, S = 9728: 986 vs 1065 us)
+  if (v3_mode_now() == 1 && S < 1536) return 0;
   const int64_t need = rt_attention_v3_ws_bytes(B, S, H);
   const bool split = ws != nullptr && need > 0 && ws_bytes >= need && RT_ALIGNED(ws, 256);
   const V3Geom G = v3_geom(S, H, split);

@@ -160,10 +160,10 @@ int rt_attention_fwd(const void* q, const void* k, const void* v, void* o,
                      int32_t B, int32_t S, int32_t H, float scale,
                      void* ws, int64_t ws_bytes, void* stream);
 
-/* Which kernel serves rt_attention_fwd (speed only; both are tested against the same references): 0 (default) = csrc/attention.hip
- * always; 1 (env RT_ATTN_V3=1) = shapes with S % 256 == 0 run csrc/attention_v3.hip — one wave per SIMD, 64 query rows per wave,
- * O and Q in asm-owned accumulator registers, hand-placed MFMA gaps (faster where the work items fill whole rounds of the chip's
- * CUs, slower at the model's S = 4608: DESIGN.md §5). mode < 0 only queries; returns the previous mode. */
+/* Which kernel serves rt_attention_fwd (speed only; both are tested against the same references): 1 (default, env RT_ATTN_V3) =
+ * shapes with S % 256 == 0 and S >= 1536 run csrc/attention_v3.hip — one wave per SIMD, 64 query rows per wave, O / Q / row sums
+ * in asm-owned accumulator registers, hand-placed MFMA gaps (S = 4608: 247 vs 264 us) —, everything else csrc/attention.hip;
+ * 0 = attention.hip always; 2 = attention_v3 wherever S % 256 == 0. mode < 0 only queries; returns the previous mode. */
 int rt_attention_variant(int32_t mode);
 
 /* BASELINE config 5, "CDNA4 fp8 MFMA attention": the same joint attention with e4m3 q, k, v and softmax numerators on

@@ -290,7 +290,7 @@ def test_attention_v3_variant(ops, gpu, B, S, H):
     dq = qkv.to(gpu, torch.bfloat16)
     prev = lib.rt_attention_variant(-1)
     try:
-        lib.rt_attention_variant(1)
+        lib.rt_attention_variant(2)
         out3 = torch.empty(B, S, d, device=gpu, dtype=torch.bfloat16)
         ops.attention(dq[..., :d], dq[..., d : 2 * d], dq[..., 2 * d :], out3, H)
         again = torch.empty_like(out3)
@@ -303,7 +303,7 @@ def test_attention_v3_variant(ops, gpu, B, S, H):
         assert bool(torch.isfinite(out3.float()).all()) and e3 < 5e-3 and torch.equal(out3, again)
         for qrow in (5, 40, 200):
             assert float((out3.float().cpu()[0, qrow, :128] - ref.reshape(B, S, d)[0, qrow, :128]).abs().max()) < 0.08, qrow
-        lib.rt_attention_variant(1)
+        lib.rt_attention_variant(2)
         inplace = dq.clone()
         ops.attention(inplace[..., :d], inplace[..., d : 2 * d], inplace[..., 2 * d :], inplace[..., :d], H)
         assert torch.equal(inplace[..., :d], out3)

@@ -28,6 +28,8 @@ VARIANTS = {
                            "      const s16x4 lo = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[dt] + kb * 8192 + s2 * 4096));\n      const s16x4 hi = tr_read((lds_cptr)(uintptr_t)(uint32_t)(va[4 + dt] + kb * 8192 + s2 * 4096));\n      return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);",
                            "      return __builtin_bit_cast(bf16x8, i32x4v{va[dt], kb, s2, 2});"),
 }
+VARIANTS["NOPARTIAL"] = lambda s: rep(s, "    if (whole) {\n#pragma unroll\n      for (int f = 0; f < 8; ++f) oc[f] = o_read(f);\n    } else {", "    if (!whole) continue;\n    if (whole) {\n#pragma unroll\n      for (int f = 0; f < 8; ++f) oc[f] = o_read(f);\n    } else {")
+VARIANTS["NOCOMBINE"] = lambda s: rep(s, "      if (!lastp) continue;", "      if (true) continue;")
 VARIANTS["MFMAONLY"] = lambda s: VARIANTS["NOLDS"](VARIANTS["NOSOFT"](VARIANTS["NODMA"](VARIANTS["NOBAR"](s))))
 VARIANTS["NOSOFT_NOLDS"] = lambda s: VARIANTS["NOLDS"](VARIANTS["NOSOFT"](s))
 objs = [os.path.join(csrc, "build", f) for f in os.listdir(os.path.join(csrc, "build")) if f.endswith(".o") and f != "attention_v3.o"]

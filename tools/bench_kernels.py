@@ -111,11 +111,11 @@ def bench_attn():
         out = torch.empty(B, S, d, device=dev, dtype=torch.bfloat16)
         res = {}
         for rnd in range(3):
-            for var in (0, 1):
+            for var in (0, 2):
                 lib.rt_attention_variant(var)
                 res.setdefault(var, []).append(timeit(lambda: ops.attention(qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:], out, H), iters=10, warm=2))
         fl = 4 * B * H * S * S * 128
-        t0, t1 = min(res[0]), min(res[1])
+        t0, t1 = min(res[0]), min(res[2])
         print(f"attn B={B} S={S} H={H}: attention.hip {t0*1e6:8.1f} us {fl/t0/1e12:7.1f} TF/s | v3 {t1*1e6:8.1f} us {fl/t1/1e12:7.1f} TF/s | {100*(t1/t0-1):+.1f} %", flush=True)
     lib.rt_attention_variant(prev)
 
