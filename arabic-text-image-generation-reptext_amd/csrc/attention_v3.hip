@@ -255,32 +255,41 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
     bf16x8 pA[2][2], pB[2][2];          // numerators [query block][k-step of 16 keys]
     bf16x8 kf[8], vf[8];                // K fragments of one 32-key half [ks]; Vᵀ fragments of one half [s2*4 + dt]
     float mxa0, mxa1, mxb0, mxb1;       // running-max chains
-    float pp[2];                        // exp2 results waiting for their add / pack (one gap later: no trans->VALU stall)
-    int pend = -1;                      // the softmax element whose second stage is pending (a compile-time constant after unrolling)
+    float tf[2], pp[2];                 // a softmax element in flight: exponent (after the fma), numerator (after the exp2)
+    int pend1 = -1, pend2 = -1;         // elements whose exp2 / whose pack is still to come (compile-time constants after unrolling)
 
-    // One softmax element o of a half (order: k-step, query block, j), against the CURRENT running max, in two stages a gap apart:
-    // A = fma + exp2, B = row-sum add + bf16 pack. The opaque uses pin every step where it is written: left alone, LLVM sinks the
-    // speculative numerators of a half below the decision branch that may redo them — all 16 in one lump, no MFMA beside them.
-    auto elem_a = [&](int o, const f32x16& Sa, const f32x16& Sb) __attribute__((always_inline)) {
+    // One softmax element o of a half (order: k-step, query block, j), against the CURRENT running max, as a three-stage pipeline a
+    // gap apart — F: fma (score·scale − m), X: exp2, C: bf16 pack — so that no instruction of a gap waits for the result of the one
+    // issued just before it (a lone wave has nobody else's instructions to fill those slots with). The opaque uses pin every step
+    // where it is written: left alone, LLVM sinks the speculative numerators of a half below the decision branch that may redo
+    // them — all 16 in one lump, no MFMA beside them.
+    auto elem_f = [&](int o, const f32x16& Sa, const f32x16& Sb) __attribute__((always_inline)) {
       const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7, r = 8 * ks + j;
-      float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA));
+      float t = __builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA);
+      asm volatile("" : "+v"(t));
+      tf[o & 1] = t;
+    };
+    auto elem_x = [&](int o) __attribute__((always_inline)) {
+      float p = __builtin_amdgcn_exp2f(tf[o & 1]);
       asm volatile("" : "+v"(p));
       pp[o & 1] = p;
     };
-    auto elem_b = [&](int o, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
+    auto elem_c = [&](int o, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
       const int ks = o >> 4, qb = (o >> 3) & 1, j = o & 7;
-      const float p = pp[o & 1];
-      P[qb][ks][j] = (__bf16)p;
+      P[qb][ks][j] = (__bf16)pp[o & 1];
       if (j & 1) asm volatile("" : "+v"(P[qb][ks]));
     };
     auto elem = [&](int o, const f32x16& Sa, const f32x16& Sb, bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
-      if (pend >= 0) elem_b(pend, P);
-      elem_a(o, Sa, Sb);
-      pend = o;
+      if (pend2 >= 0) elem_c(pend2, P);
+      if (pend1 >= 0) elem_x(pend1);
+      elem_f(o, Sa, Sb);
+      pend2 = pend1;
+      pend1 = o;
     };
     auto elem_flush = [&](bf16x8 (&P)[2][2]) __attribute__((always_inline)) {
-      if (pend >= 0) elem_b(pend, P);
-      pend = -1;
+      if (pend2 >= 0) elem_c(pend2, P);
+      if (pend1 >= 0) { elem_x(pend1); elem_c(pend1, P); }
+      pend1 = pend2 = -1;
     };
     // step k (0..7) of the max chain over the 16 scores of one fragment
     auto maxstep = [&](int k, const f32x16& s, float& m0, float& m1) __attribute__((always_inline)) {
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void attention_v3_kernel(const bf16_
 #pragma unroll
         for (int f = 0; f < 10; ++f) o_scale(f, (f & 1) ? alB : alA);
 #pragma unroll
-        for (int o = 0; o < 16; ++o) { elem_a(o, Sa, Sb); elem_b(o, P); }
+        for (int o = 0; o < 16; ++o) { elem_f(o, Sa, Sb); elem_x(o); elem_c(o, P); }
       }
     };
     // LDS read addresses of the stage in use: ka = K rows of one stage, va = Vᵀ blocks of one stage. They are moved to the next

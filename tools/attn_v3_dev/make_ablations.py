@@ -18,10 +18,9 @@ VARIANTS = {
     "BASE": lambda s: s,
     "NODMA": lambda s: rep(s, "if (g >= 2 && g < 18 && (g & 1) == 0) dma_piece(sbp, so2, (g - 2) >> 1);", "(void)so2;"),
     "NOBAR": lambda s: rep(s, '        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __builtin_amdgcn_s_barrier();\n        V3_SB();', "        V3_SB();"),
-    "NOEXP": lambda s: rep(s, "float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA));",
-                           "float p = __builtin_fmaf(qb ? Sb[r] : Sa[r], scale_log2, qb ? -mB : -mA);"),
+    "NOEXP": lambda s: rep(s, "float p = __builtin_amdgcn_exp2f(tf[o & 1]);", "float p = tf[o & 1];"),
     "NOL": lambda s: rep(s, "        else mfma_l(h & 1, P[h & 1][s2]);", "        else { }"),
-    "NOSOFT": lambda s: rep(rep(s, "      if (pend >= 0) elem_b(pend, P);\n      elem_a(o, Sa, Sb);\n      pend = o;", "      (void)o;"),
+    "NOSOFT": lambda s: rep(rep(s, "      if (pend2 >= 0) elem_c(pend2, P);\n      if (pend1 >= 0) elem_x(pend1);\n      elem_f(o, Sa, Sb);\n      pend2 = pend1;\n      pend1 = o;", "      (void)o;"),
                             "      if (k == 0) m0 = max3f(s[0], s[1], s[2]);", "      if (true) { m0 = 0.f; m1 = 0.f; }\n      else if (k == 0) m0 = max3f(s[0], s[1], s[2]);"),
     "NOLDS": lambda s: rep(rep(s, "      return *(const __attribute__((address_space(3))) bf16x8*)((lds_cptr)(uintptr_t)(uint32_t)(ka[ks] + kb * 8192));",
                                "      return __builtin_bit_cast(bf16x8, i32x4v{ka[ks], kb, ks, 1});"),
