@@ -14,6 +14,7 @@ for l in lines[hot:]:
         if cur is not None:
             gaps.append(cur)
         if n > 72:
+            cur = None
             break
         cur = dict(v=0, x=0, ds=0, dma=0, nop=0, w=0, s=0)
     elif cur is not None:
