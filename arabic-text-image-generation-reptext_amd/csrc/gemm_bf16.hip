@@ -511,9 +511,13 @@ int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-int g_tile_mode = -1;      // bit 0: 288x192 launches, bit 1: narrow tail tiles; -1 = not read yet (RT_GEMM_TILES, default 3)
+// bit 0: 288x192 launches, bit 1: narrow tail tiles; -1 = not read yet (RT_GEMM_TILES). Default 0: measured on MI355X the fuller last
+// round buys nothing — interleaved A/B at the model's shapes: 4608x3072x15360 on 256 tiles of 288x192 348 us vs 342 us on 216 tiles of
+// 256x256; q|k|v -1.6 %, ff1 -0.8 %; in the model 1210 vs 1213 TFLOP/s. The chip is power-limited: CUs left idle in a last round give
+// their share of the clock to the busy ones, and the narrower tiles re-read more operand bytes per FLOP.
+int g_tile_mode = -1;
 int tile_mode_now() {
-  if (g_tile_mode < 0) g_tile_mode = env_int("RT_GEMM_TILES", 3) & 3;
+  if (g_tile_mode < 0) g_tile_mode = env_int("RT_GEMM_TILES", 0) & 3;
   return g_tile_mode;
 }
 

@@ -85,8 +85,9 @@ int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* 
 /* Tile selection of rt_gemm_bf16 (speed only: every output element is accumulated in the same K order by every tile shape, so
  * results are bit-identical in all modes). Bit 0: a single problem whose M x N is a whole number of 288x192 tiles and fills the
  * chip's CUs better that way (M = 4608, N = 3072: exactly 256 tiles) runs on them; bit 1: a launch of several rounds of
- * 256x256 tiles gives the columns of its poorly filled last round to 256x192 or 256x128 tiles. Default 3 (env RT_GEMM_TILES).
- * mode >= 0 sets it, mode < 0 only queries; returns the previous mode. For A/B measurements and tests. */
+ * 256x256 tiles gives the columns of its poorly filled last round to 256x192 or 256x128 tiles. Default 0 (env RT_GEMM_TILES): on
+ * MI355X neither pays (the chip is power-limited; measurements in DESIGN.md §5). mode >= 0 sets it, mode < 0 only queries;
+ * returns the previous mode. For A/B measurements and tests. */
 int rt_gemm_tile_mode(int32_t mode);
 
 /* Same contraction and epilogue on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, fp32 accumulate, block scales fixed to
