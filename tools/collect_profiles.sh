@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence in one go (run on the GPU box from the repo root): tools/collect_profiles.sh <tag>   e.g. r02
 # Writes under gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -20,18 +20,30 @@ echo "[5] MFMA / LDS / wave-time counters, attention and GEMM alone"
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
 P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
 P3="GRBM_GUI_ACTIVE"
+P4="FETCH_SIZE"
+P5="WRITE_SIZE"
 for K in attn gemm; do
   i=0
-  for P in "$P1" "$P2" "$P3"; do
+  for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
     i=$((i+1))
     rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_${K}_p$i -- python3 $R/tools/prof_one.py $K > /dev/null 2> $OUT/pmc_${K}_p$i.err
   done
 done
-for d in fetch_bf16 write_bf16 fetch_fp8 write_fp8 pmc_attn_p1 pmc_attn_p2 pmc_attn_p3 pmc_gemm_p1 pmc_gemm_p2 pmc_gemm_p3; do
+# the 2-waves-per-SIMD attention kernel alone, for comparison (round 3: attention_v3 serves S >= 1536 by default)
+export RT_ATTN_V3=0
+i=0
+for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
+  i=$((i+1))
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_attnold_p$i -- python3 $R/tools/prof_one.py attn > /dev/null 2> $OUT/pmc_attnold_p$i.err
+done
+unset RT_ATTN_V3
+echo "[5b] VAE decode alone: kernel trace + stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_vae -- python3 $R/tools/prof_vae.py > /dev/null 2> $OUT/stats_vae.err
+for d in fetch_bf16 write_bf16 fetch_fp8 write_fp8 pmc_attn_p1 pmc_attn_p2 pmc_attn_p3 pmc_attn_p4 pmc_attn_p5 pmc_gemm_p1 pmc_gemm_p2 pmc_gemm_p3 pmc_gemm_p4 pmc_gemm_p5 pmc_attnold_p1 pmc_attnold_p2 pmc_attnold_p3 pmc_attnold_p4 pmc_attnold_p5; do
   python3 $R/tools/pmc_summary.py $OUT/$d > $OUT/$d.json
   rm -rf $OUT/$d                       # the raw per-dispatch CSVs are large; the per-kernel means are what is kept
 done
-for d in stats_bf16 stats_fp8; do
+for d in stats_bf16 stats_fp8 stats_vae; do
   cp $OUT/$d/*/*kernel_stats.csv $OUT/${d}_kernel_stats.csv
   rm -rf $OUT/$d
 done
