@@ -184,13 +184,11 @@ class GemmTimer:
 
 
 def pmc_traffic_bytes(kernel_key: str):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_traffic_pmc.json: rocprofv3 --pmc
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r03_traffic_pmc.json, else the last earlier round's: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE over this same command, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
     Counters cannot be read from inside the timed process, so the value is the last profiled one; null when absent."""
     try:
-        path = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
-        if not os.path.isfile(path):
-            path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_pmc.json") for r in (3, 2, 1)) if os.path.isfile(p))
         with open(path) as f:
             d = json.load(f)
         if kernel_key.startswith("fp8:"):          # the passes over `bench.py --precision fp8`
@@ -474,7 +472,7 @@ def main():
             peak, kname, tkey = 2500.0, "gemm_pp_kernel<bf16> (rt_gemm_bf16)", "gemm"
         else:                                    # dominant kernel of the fp8 run: the e4m3 instantiation, priced at the dense fp8 peak
             n_launch, fl, sec = gt.result(fp8=True)
-            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", "fp8:gemm_pp_kernel<true>"
+            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", "fp8:gemm_pp_kernel"
         ach = fl / sec / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic_bytes(tkey) if tkey else None, "kernel": kname, "launches": n_launch,
@@ -486,7 +484,8 @@ def main():
         na, fla, seca = gt.attention_result()
         if na:
             pk = 2500.0 if args.precision != "fp8" else 5000.0
-            roofline["attention_kernel"] = {"kernel": "attention_fwd_kernel" if args.precision != "fp8" else "attention_fp8_kernel", "launches": na,
+            roofline["attention_kernel"] = {"kernel": ("attention_v3_kernel (attention_fwd_kernel for S < 1536 or S % 256 != 0)" if args.precision != "fp8"
+                                                       else "attention_fp8_kernel"), "launches": na,
                                             "avg_launch_us": round(seca / na * 1e6, 2), "achieved": round(fla / seca / 1e12, 1), "peak": pk,
                                             "frac": round(fla / seca / (pk * 1e12), 4)}
         if args.precision != "bf16":

@@ -26,6 +26,7 @@ for l in lines[hot:]:
         elif l.startswith("s_waitcnt"): cur["w"] += 1
         elif l.startswith("s_"): cur["s"] += 1
 est = lambda g: 8 + 8 * g["x"] + 4 * (g["v"] + g["ds"] + g["nop"] + g["w"] + g["s"]) + 60 * g["dma"]
+tail, gaps = gaps[-1], gaps[:-1]      # the 72nd gap runs from the tile's last MFMA to the next MFMA in PROGRAM order (back-edge, other tile variants): not a steady-state gap
 tot = {k: sum(g[k] for g in gaps) for k in gaps[0]}
 print(f"{len(gaps)} gaps; totals {tot}; issue estimate {sum(est(g) for g in gaps)} cycles, pipe floor {32 * len(gaps)}; over-32 excess {sum(max(0, est(g) - 32) for g in gaps)}")
 for i in range(0, len(gaps), 18):
