@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void prep_vt_kernel(const bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t* __restrict__ qk8, const uint8_t* __restrict__ vt8,
                                                                    bf16_t* O, int64_t ldo, int64_t stride_ob, int S, int S64, int H,
-                                                                   float scale_log2) {
+                                                                   float scale_log2, uint8_t* O8, int64_t ldo8, int64_t stride_ob8,
+                                                                   uint8_t* bsc, int64_t bsc_plane, int64_t bsc_rows) {
   __shared__ __attribute__((aligned(16))) char smem[2 * SLOT_B];   // [slot][K 8 KiB | Vᵀ 8 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -325,6 +326,39 @@ __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + wave * 32 + l31;
+  if (O8) {
+    // e4m3 + E8M0 block scales (rt_attention_fp8_fwd_mx): a 32-column block of the output row = one dt; the lane holds 16 of its
+    // columns, lane ^ 32 the other 16. Same rule as rt_quantize_mx_fp8 on the fp32 value o * inv; the next GEMM reads it as A.
+    const bool valid = qrow < S;
+    const int m = min(qrow, S - 1);
+    uint8_t* orow = O8 + b * stride_ob8 + (int64_t)m * ldo8 + head * DH;
+    uint32_t sbytes = 0;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float am = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(o_acc[dt][r]));
+      am = rt_max_over_halves(am * inv);
+      const int sb = rt_mx_scale_byte(am);
+      const float f = inv * rt_mx_inv_scale(sb);
+      sbytes |= (uint32_t)sb << (8 * dt);
+      int w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        w[g] = 0;
+        w[g] = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(o_acc[dt][4 * g + 0] * f), sat448(o_acc[dt][4 * g + 1] * f), w[g], false);
+        w[g] = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(o_acc[dt][4 * g + 2] * f), sat448(o_acc[dt][4 * g + 3] * f), w[g], true);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const auto x = __builtin_amdgcn_permlane32_swap((unsigned)w[g], (unsigned)w[g + 1], false, false);
+        if (valid) *reinterpret_cast<u32x2*>(orow + dt * 32 + 8 * (g + hh)) = u32x2{x[0], x[1]};
+      }
+    }
+    if (valid && hh == 0)
+      *reinterpret_cast<uint32_t*>(bsc + (int64_t)(head >> 1) * bsc_plane + ((int64_t)b * bsc_rows + m) * 8 + (head & 1) * 4) = sbytes;
+    return;
+  }
   const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
   if (wide) {
     rt_store_o_rows(O + b * stride_ob + (int64_t)min(qrow, S - 1) * ldo + head * DH, qrow < S, hh, o_acc, inv);
@@ -380,6 +414,23 @@ extern "C" int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, i
   const int NI = H * ((S + BQ - 1) / BQ);
   const dim3 grid(8 * ((NI + 7) / 8), B);
   hipLaunchKernelGGL(attention_fp8_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream, (const uint8_t*)qk8, (const uint8_t*)vt8,
-                     (bf16_t*)o, ldo, stride_ob, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE));
+                     (bf16_t*)o, ldo, stride_ob, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE), (uint8_t*)nullptr,
+                     (int64_t)0, (int64_t)0, (uint8_t*)nullptr, (int64_t)0, (int64_t)0);
+  return rt_hip_status();
+}
+
+extern "C" int rt_attention_fp8_fwd_mx(const void* qk8, const void* vt8, void* o8, int64_t ldo8, int64_t stride_ob8, uint8_t* bscale,
+                                       int64_t plane, int64_t bscale_rows, int32_t B, int32_t S, int32_t H, float scale, void* stream) {
+  if (!qk8 || !vt8 || !o8 || !bscale || B < 1 || S < 1 || H < 1) return RT_E_BADARG;
+  if (!RT_ALIGNED(qk8, 16) || !RT_ALIGNED(vt8, 16) || !RT_ALIGNED(o8, 8) || ldo8 % 8 || stride_ob8 % 8 || !RT_ALIGNED(bscale, 4) || plane % 8)
+    return RT_E_ALIGN;
+  if (ldo8 < (int64_t)H * DH || H % 2 != 0 || plane < ((int64_t)(B - 1) * bscale_rows + S) * 8) return RT_E_SHAPE;
+  if ((int64_t)(S + BKV) * 2 * H * DH >= (int64_t)1 << 31) return RT_E_SHAPE;
+  const int S64 = (S + BKV - 1) / BKV * BKV;
+  const int NI = H * ((S + BQ - 1) / BQ);
+  const dim3 grid(8 * ((NI + 7) / 8), B);
+  hipLaunchKernelGGL(attention_fp8_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream, (const uint8_t*)qk8, (const uint8_t*)vt8,
+                     (bf16_t*)nullptr, (int64_t)0, (int64_t)0, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE), (uint8_t*)o8,
+                     ldo8, stride_ob8, bscale, plane, bscale_rows);
   return rt_hip_status();
 }

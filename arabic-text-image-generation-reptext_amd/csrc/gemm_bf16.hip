@@ -133,6 +133,9 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     const int mc = min(m, g.M - 1);
     const float rs = g.rowscale ? g.rowscale[(int64_t)bidx * g.stride_rowscale + mc % rpb] * g.alpha : g.alpha;
     u32x2 packed[NJ];                                  // bf16 results of the fragment columns (wide-store path)
+    f32x4 vrow[NJ];                                    // e4m3 + block-scale output: the row's values before quantisation
+    // MX output (rt_gemm_group::c8): tile-uniform, c8_from is a multiple of the tile width
+    const bool to8 = FP8 && g.c8 != nullptr && ncol >= g.c8_from;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n = ncol + 16 * j;
@@ -157,7 +160,8 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
         else { v[0] += bf16lo(rcur[j][0]); v[1] += bf16hi(rcur[j][0]); v[2] += bf16lo(rcur[j][1]); v[3] += bf16hi(rcur[j][1]); }
       }
       if (g.add2) { v[0] += bf16lo(acur[j][0]); v[1] += bf16hi(acur[j][0]); v[2] += bf16lo(acur[j][1]); v[3] += bf16hi(acur[j][1]); }
-      if (m < g.M && nok[j]) {
+      vrow[j] = v;
+      if (m < g.M && nok[j] && !to8) {
         const int64_t coff = (int64_t)bidx * g.strideC + (int64_t)m * g.ldc + n;
         if constexpr (OUT_F32) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + coff) = v;
@@ -173,13 +177,44 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
         packed[j][1] = pack_bf16x2(v[2], v[3]);
       }
     }
+    if constexpr (FP8 && !OUT_F32 && NJ % 2 == 0) {
+      // e4m3 + E8M0 block scales: a 32-column block = the fragment pair (jp, jp+1), spread over the four 16-lane rows of the wave
+      // (4 columns of each fragment per lane). Block maximum = 8 values in the lane, then across the lane rows; every lane derives
+      // the same scale byte, scales its 8 values by the exact power of two, converts (RNE) and — after the same v_permlane16_swap
+      // as the wide bf16 store — owns 8 consecutive bytes. One lane per row writes the wave's scale bytes (2 per fragment pair).
+      if (to8) {
+        const int c = (ncol >> 2) & 3;
+#pragma unroll
+        for (int jp = 0; jp + 1 < NJ; jp += 2) {
+          float am = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(vrow[jp][e]), fabsf(vrow[jp + 1][e])));
+          am = rt_max_over_lane_rows(am);
+          const int sb = rt_mx_scale_byte(am);
+          const float inv = rt_mx_inv_scale(sb);
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(vrow[jp][0] * inv, vrow[jp][1] * inv, w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(vrow[jp][2] * inv, vrow[jp][3] * inv, w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(vrow[jp + 1][0] * inv, vrow[jp + 1][1] * inv, w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(vrow[jp + 1][2] * inv, vrow[jp + 1][3] * inv, w1, true);
+          const auto x = __builtin_amdgcn_permlane16_swap((unsigned)w0, (unsigned)w1, false, false);
+          const int n8 = (ncol - 4 * c) + 16 * (jp + (c & 1)) + 8 * (c >> 1);       // first of this lane's 8 columns
+          const int k8 = n8 - g.c8_from;                                             // column of the consumer's A
+          if (m < g.M && n8 < g.N)
+            *reinterpret_cast<u32x2*>(g.c8 + (int64_t)bidx * g.stride_c8 + (int64_t)m * g.ldc8 + k8) = u32x2{x[0], x[1]};
+          const int kb = (ncol - 4 * c) + 16 * jp - g.c8_from;                       // first column of the block
+          if (c == 0 && m < g.M && kb + g.c8_from < g.N)
+            g.c_bscale[(int64_t)(kb >> 8) * g.c_bscale_plane + ((int64_t)bidx * g.c_bscale_rows + m) * 8 + ((kb & 255) >> 5)] = (uint8_t)sb;
+        }
+      }
+    }
     if constexpr (!OUT_F32) {
       // Wide store: the four 16-lane groups c of a wave hold columns 4c..4c+3 of each 16-column fragment — 8 bytes per lane.
       // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another; applied to the registers
       // of fragments (j, j+1) it leaves every lane with 8 CONSECUTIVE columns (its own 4 plus its neighbour group's): groups
       // 0/2 take fragment j, groups 1/3 fragment j+1. Same bytes, same addresses, half the store instructions (the store tail of
       // a tile is issue-bound). An odd last fragment column is stored narrow (above).
-      if (wide) {
+      if (wide && !to8) {
         const int c = (ncol >> 2) & 3;                // this lane's 16-lane group
 #pragma unroll
         for (int jp = 0; jp + 1 < NJ; jp += 2) {
@@ -238,9 +273,20 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 //              The MFMA's lane group j (lane>>4) is given the two 16-byte chunks j and j+4 of the row as its 32 k-values —
 //              the chunks the bf16 form reads for its k-steps 0 and 1 — for both operands alike, so the contraction still
 //              covers every k exactly once and the reads keep their conflict-free pattern.
-template <bool FP8, class G_>
+//
+// MX = true (e4m3 only): A carries one E8M0 block scale per 32 K-elements (rt_gemm_group::a_bscale). The 256 rows x 8 bytes a tile
+//              needs per PAIR of K-tiles are one contiguous 2-KiB run of the scale plane: every wave fetches 256 B of it with one 4-byte
+//              LDS-DMA piece, issued together with part a0 of every EVEN K-tile (so it is retired by the waits that retire a0)
+//              into a 2 x 2 KiB ring behind the operand buffers. A lane reads the byte of its (row, 32-element block) with one
+//              ds_read_u8 per fragment next to the fragment itself and hands it to the MFMA as the scale of its second operand
+//              (the activation rows; the weights keep scale 2^0). Measured (tools/mx_dev/probe_scales.py): in the instruction's own
+//              K order lane group g holds k = 16g..16g+15 in its first four registers and 64+16g.. in the other four — the chunks
+//              j and j+4 read above, so the hardware's K order IS the memory order — and the byte supplied by lane group b scales
+//              K-block b (k = 32b..32b+31) of that lane's row, whichever lanes hold those values: lane (row, j) supplies block j.
+template <bool FP8, class G_, bool MX = false>
 __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int m0, int n0, bool wide_store, char* smem) {
   using T = G_;
+  static_assert(!MX || FP8, "block scales belong to the e4m3 form");
   constexpr int ESZ = FP8 ? 1 : 2;                   // bytes per operand element
   constexpr int BKE = 128 / ESZ;                     // elements per K-tile
   constexpr int NPC = T::PA0 + T::PB0 + T::PB1 + T::PA1;          // pieces per wave and K-tile
@@ -309,6 +355,19 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
       __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
                                                (int)src[first + q], koff, 0, 0);
   };
+  // MX: the scale piece of K-tile pair `pair` -> ring slot pair & 1. Lane l of wave w covers row 32w + l/2, K-tile l & 1 of the pair.
+  constexpr int SC_OFF = 2 * T::BUF_BYTES;
+  __amdgpu_buffer_rsrc_t rsrcS;
+  int sc_src = 0;
+  if constexpr (MX) {
+    rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.a_bscale), 0, -1, 0x00020000);
+    const int row = wave * 32 + (lane >> 1);
+    sc_src = (int)(((int64_t)bidx * g.a_bscale_rows + min(m0 + row, g.M - 1)) * 8 + (lane & 1) * 4);
+  }
+  auto issue_scales = [&](int pair) {
+    if constexpr (MX)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, LDS_PTR(smem + SC_OFF + (pair & 1) * 2048 + wave * 256), 4, sc_src, pair * (int)g.a_bscale_plane, 0, 0);
+  };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
@@ -318,6 +377,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   const int sw = (lane >> 1) & 7;
   const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
+  const int sc_rd = SC_OFF + (wm * T::WMR + l15) * 8 + (lane >> 4);         // MX: + slot*2048 + fragment*128 + (K-tile & 1)*4
   const int a_base = wm * T::WMR * 128;
   const int w_base = T::A_BYTES + wn * T::WNC * 128;
 
@@ -328,6 +388,9 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     for (int j = 0; j < T::NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[T::NIH][2];        // current a-half: [frag][kk]
   bf16x8 wf[2][T::NJH][2];     // both b-halves: [half][frag][kk]
+  int sc[T::NIH];              // MX: block scale byte of the current a-half's fragments for this K-tile
+#pragma unroll
+  for (int i = 0; i < T::NIH; ++i) sc[i] = 0x7F;
 
 #define RT_NIH(ah) ((ah) ? T::NI1 : T::NI0)
 #define RT_NJH(bh) ((bh) ? T::NJ1 : T::NJ0)
@@ -335,6 +398,11 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i) {                                                        \
     af[i][0] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd0);                     \
     af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd1);                     \
+  }
+#define RT_READ_S(ah, kt_)                                                                                        \
+  if constexpr (MX) {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                        \
+      sc[i] = *reinterpret_cast<const uint8_t*>(smem + sc_rd + (((kt_) >> 1) & 1) * 2048 + ((ah)*T::NI0 + i) * 128 + ((kt_) & 1) * 4); \
   }
 #define RT_READ_B(bh)                                                                                             \
   _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j) {                                                        \
@@ -350,7 +418,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
         _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j)                                                    \
           acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
               RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j], \
-              0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* 2^0 */, 0, 0x7F7F7F7F);                            \
+              0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* weights: 2^0 */, 0, MX ? sc[i] : 0x7F7F7F7F);     \
     } else {                                                                                                      \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                            \
         _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                    \
@@ -362,18 +430,23 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   } while (0)
 
   const int nk = g.K / BKE;
-  issue(P0{}, 0, 0); issue(P1{}, 0, 0); issue(P2{}, 0, 0); issue(P3{}, 0, 0);
-  rt_vmcnt<T::PB1 + T::PA1>();                 // a0, b0 of tile 0 landed (younger: b1, a1)
+  issue(P0{}, 0, 0); issue_scales(0); issue(P1{}, 0, 0); issue(P2{}, 0, 0); issue(P3{}, 0, 0);
+  rt_vmcnt<T::PB1 + T::PA1>();                 // a0 (+ scales), b0 of tile 0 landed (younger: b1, a1)
   RT_BAR();
   if (wm == 1) RT_BAR();                       // stagger waves 4-7 by one barrier
 
+  // MX: the scale piece of the NEXT pair of K-tiles goes out with part a0 of every even tile, i.e. in the odd iterations. The counted
+  // waits keep their immediates: with the extra piece among the younger ones they ask for one more of the older pieces (issued a
+  // phase earlier) than strictly needed — conservative, never too weak. (Unrolling the loop by two to give the odd iterations their
+  // own immediates cost 18 spilled VGPRs: the compiler then keeps both buffers' address sets live.)
   for (int kt = 0; kt + 1 < nk; ++kt) {
     const char* tb = smem + (kt & 1) * T::BUF_BYTES;
     const int nb = (kt & 1) ^ 1;
     const int koff = (kt + 1) * 128;           // bytes
     // ---- phase 1: (a0,b0)
-    RT_READ_A(0); RT_READ_B(0);
+    RT_READ_A(0); RT_READ_S(0, kt); RT_READ_B(0);
     issue(P0{}, nb, koff);
+    if constexpr (MX) { if (kt & 1) issue_scales((kt + 1) >> 1); }
     rt_vmcnt<T::PA1 + T::PA0>();               // b1(kt) landed (younger: a1(kt), a0(kt+1))
     RT_BAR(); RT_MFMA(0, 0); RT_BAR();
     // ---- phase 2: (a0,b1)
@@ -382,28 +455,30 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     rt_vmcnt<T::PA0 + T::PB0>();               // a1(kt) landed (younger: a0(kt+1), b0(kt+1))
     RT_BAR(); RT_MFMA(0, 1); RT_BAR();
     // ---- phase 3: (a1,b1)
-    RT_READ_A(1);
+    RT_READ_A(1); RT_READ_S(1, kt);
     issue(P2{}, nb, koff);
     RT_BAR(); RT_MFMA(1, 1); RT_BAR();
     // ---- phase 4: (a1,b0)  (b0 still in registers)
     issue(P3{}, nb, koff);
-    rt_vmcnt<T::PB1 + T::PA1>();               // a0(kt+1), b0(kt+1) landed (younger: b1(kt+1), a1(kt+1))
+    rt_vmcnt<T::PB1 + T::PA1>();               // a0(kt+1) (+ scales), b0(kt+1) landed (younger: b1(kt+1), a1(kt+1))
     RT_BAR(); RT_MFMA(1, 0); RT_BAR();
   }
   {                                            // last K-tile: nothing left to issue, drain
-    const char* tb = smem + ((nk - 1) & 1) * T::BUF_BYTES;
-    RT_READ_A(0); RT_READ_B(0);
+    const int kt = nk - 1;
+    const char* tb = smem + (kt & 1) * T::BUF_BYTES;
+    RT_READ_A(0); RT_READ_S(0, kt); RT_READ_B(0);
     rt_vmcnt<0>();
     RT_BAR(); RT_MFMA(0, 0); RT_BAR();
     RT_READ_B(1);
     RT_BAR(); RT_MFMA(0, 1); RT_BAR();
-    RT_READ_A(1);
+    RT_READ_A(1); RT_READ_S(1, kt);
     RT_BAR(); RT_MFMA(1, 1); RT_BAR();
     RT_BAR(); RT_MFMA(1, 0); RT_BAR();
   }
   if (wm == 0) RT_BAR();                       // balance the stagger barrier
 #undef RT_READ_A
 #undef RT_READ_B
+#undef RT_READ_S
 #undef RT_MFMA
 #undef RT_CAT8
 #undef RT_NIH
@@ -437,7 +512,7 @@ __device__ __forceinline__ void panel_walk(int t, int tiles_m, int tiles_n, int&
 typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
 
 // One geometry for the whole launch (G_ = Geo256: every ordinary launch; Geo288: M x N a whole number of 288x192 tiles).
-template <bool FP8, class G_>
+template <bool FP8, class G_, bool MX = false>
 __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -460,7 +535,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
   t -= bidx * tiles_per_batch;
   int tm, tn;
   panel_walk(t, G.tiles_m, G.tiles_n, tm, tn);
-  gemm_tile<FP8, G_>(G.g, bidx, tm * G_::BM, tn * G_::BN, G.wide_store != 0, smem);
+  gemm_tile<FP8, G_, MX>(G.g, bidx, tm * G_::BM, tn * G_::BN, G.wide_store != 0, smem);
 }
 
 // Two geometries in one launch: the 256-wide tiles of every group first, then the narrow tiles (GN_) of the columns the host
@@ -534,6 +609,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   Launch L{};
   L.ngroups = ngroups;
   int total = 0;
+  bool mx = false;
   const int bke = fp8 ? 128 : BK;                     // elements per K-tile
   const int al = fp8 ? 16 : 8;                        // elements per 16 bytes
   const int64_t esz = fp8 ? 1 : 2;
@@ -555,6 +631,20 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     if (g.bias && !RT_ALIGNED(g.bias, 8)) return RT_E_ALIGN;
     if (g.gate && (!RT_ALIGNED(g.gate, 16) || g.gate_ld % 4)) return RT_E_ALIGN;
     if (fp8 && g.w_scale && !RT_ALIGNED(g.w_scale, 16)) return RT_E_ALIGN;
+    if (fp8) {                                          // MX block scales: all groups of a launch with A scales, or none
+      if ((g.a_bscale != nullptr) != (groups[0].a_bscale != nullptr)) return RT_E_BADARG;
+      if (g.a_bscale) {
+        mx = true;
+        if (g.K % 256 != 0 || g.a_bscale_plane % 8 != 0 || g.a_bscale_plane < (int64_t)g.M * 8) return RT_E_SHAPE;
+        if ((int64_t)(g.K / 256) * g.a_bscale_plane >= ((int64_t)1 << 31) || ((int64_t)g.batch * g.a_bscale_rows + g.M) * 8 >= ((int64_t)1 << 31)) return RT_E_SHAPE;
+        if (!RT_ALIGNED(g.a_bscale, 4)) return RT_E_ALIGN;
+      }
+      if (g.c8) {
+        if (g.out_f32 || !g.c_bscale) return RT_E_BADARG;
+        if (g.c8_from < 0 || g.c8_from % 256 != 0 || g.c8_from >= g.N || (g.N - g.c8_from) % 32 != 0 || g.c_bscale_plane % 8 != 0) return RT_E_SHAPE;
+        if (!RT_ALIGNED(g.c8, 8) || g.ldc8 % 8 || g.stride_c8 % 8) return RT_E_ALIGN;
+      }
+    }
     L.grp[i].g = g;
     L.grp[i].tiles_m = (g.M + Geo256::BM - 1) / Geo256::BM;
     L.grp[i].tiles_n = (g.N + Geo256::BN - 1) / Geo256::BN;
@@ -566,6 +656,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   if (!attr_done) {
     int e = set_lds(gemm_pp_kernel<false, Geo256>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_pp_kernel<true, Geo256>, Geo256::LDS_BYTES);
+    if (!e) e = set_lds(gemm_pp_kernel<true, Geo256, true>, Geo256::LDS_BYTES + 4096);
     if (!e) e = set_lds(gemm_pp_kernel<false, Geo288>, Geo288::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo192>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo128>, Geo256::LDS_BYTES);
@@ -574,7 +665,8 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   }
   hipStream_t st = (hipStream_t)stream;
   if (fp8) {
-    hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+    if (mx) hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256, true>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES + 4096, st, L);
+    else hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
     return rt_hip_status();
   }
   const int cus = num_cus();

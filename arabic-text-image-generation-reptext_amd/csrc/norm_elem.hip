@@ -192,6 +192,44 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const void* __re
   }
 }
 
+// MX block quantisation (reptext_hip.h: rt_quantize_mx_fp8): 8 elements per thread, 4 threads per 32-element block.
+template <bool X_F32>
+__global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const void* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ldo,
+                                                              uint8_t* __restrict__ bscale, int64_t plane, int rows, int D) {
+  const int per_row = D >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int row = (int)(idx / per_row);
+  const int col = (int)(idx - (int64_t)row * per_row) * 8;
+  const bool ok = row < rows;                             // whole 4-lane groups are in or out together (per_row % 32 == 0)
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = 0.f;
+  if (ok) {
+    if (X_F32) {
+      const float* p = reinterpret_cast<const float*>(x) + (int64_t)row * ldx + col;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y[i] = a[i]; y[4 + i] = bb[i]; }
+    } else {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(x) + (int64_t)row * ldx + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y[2 * i] = bf16lo(u[i]); y[2 * i + 1] = bf16hi(u[i]); }
+    }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(y[i]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1));
+  amax = fmaxf(amax, __shfl_xor(amax, 2));
+  const int sb = rt_mx_scale_byte(amax);
+  const float inv = rt_mx_inv_scale(sb);
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = fminf(fmaxf(y[i] * inv, -E4M3_MAX), E4M3_MAX);
+  *reinterpret_cast<u32x2*>(out + (int64_t)row * ldo + col) = pack_e4m3x8(y);
+  if ((threadIdx.x & 3) == 0) bscale[(int64_t)(col >> 8) * plane + (int64_t)row * 8 + ((col & 255) >> 5)] = (uint8_t)sb;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // q/k RMSNorm(128) + RoPE in place. 16 lanes per 128-vector (8 elements = 4 rotation pairs each),
 // 4 vectors per wave. Grid covers B*S*H*2 vectors (q and k).
@@ -544,6 +582,19 @@ int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, i
   else if (nch <= 30) QR_LAUNCH(30);
   else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, grid, block, 0, st, x, ldx, (uint8_t*)out, ldo, scale, rows, D);
 #undef QR_LAUNCH
+  return rt_hip_status();
+}
+
+int rt_quantize_mx_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, uint8_t* bscale, int64_t plane,
+                       int32_t rows, int32_t D, void* stream) {
+  if (!x || !out || !bscale || rows < 1 || D < 256) return RT_E_BADARG;
+  if (D % 256 || plane < (int64_t)rows * 8) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8) return RT_E_ALIGN;
+  const int64_t n = (int64_t)rows * (D / 8);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_f32) hipLaunchKernelGGL(quantize_mx_fp8_kernel<true>, grid, block, 0, st, x, ldx, (uint8_t*)out, ldo, bscale, plane, rows, D);
+  else hipLaunchKernelGGL(quantize_mx_fp8_kernel<false>, grid, block, 0, st, x, ldx, (uint8_t*)out, ldo, bscale, plane, rows, D);
   return rt_hip_status();
 }
 

@@ -115,3 +115,36 @@ __device__ __forceinline__ rt_srd_t rt_make_srd(const void* base) {
 __device__ __forceinline__ void rt_dma16_asm(rt_srd_t srd, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
+
+// ---- MX block scales (config 5): one E8M0 byte per 32 consecutive K-elements of an activation row -------------------------------
+// Scale of a block with maximum magnitude amax: the smallest power of two 2^e with amax <= 448 * 2^e (448 = 1.75 * 2^8 is e4m3's
+// largest finite value), so no element saturates. Returned as the biased byte s = e + 127, clamped to [1, 253] (an all-zero block
+// gets s = 1; its elements are zero whatever the scale). From the float's own fields: e = E - 127 - 8, one more when the mantissa
+// exceeds 1.75's. oracle/: mx_scale_byte.
+__device__ __forceinline__ int rt_mx_scale_byte(float amax) {
+  const uint32_t u = __float_as_uint(amax);
+  int s = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
+  return min(max(s, 1), 253);
+}
+// 2^-(s-127) as a float, exact for s in [1, 253]
+__device__ __forceinline__ float rt_mx_inv_scale(int s) { return __uint_as_float((uint32_t)(254 - s) << 23); }
+
+// max over the four lanes {l&15 + 16c, c = 0..3} (the 16-lane rows of a wave), result in all four: v_permlane16_swap exchanges the
+// odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half. Inline asm
+// for the reason given at the row-max exchange of attention.hip (hipcc folds max(result[0], result[1]) of the builtins).
+__device__ __forceinline__ float rt_max_over_lane_rows(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  float m = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  a = __builtin_bit_cast(unsigned, m);
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+// max over the lane pair (l, l ^ 32)
+__device__ __forceinline__ float rt_max_over_halves(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+

@@ -1,3 +1,3 @@
 #include "rt_common.h"
-extern "C" const char* rt_version(void) { return "reptext_hip abi7 gfx950"; }
-extern "C" int rt_abi_version(void) { return 7; }
+extern "C" const char* rt_version(void) { return "reptext_hip abi8 gfx950"; }
+extern "C" int rt_abi_version(void) { return 8; }

@@ -15,7 +15,7 @@ LIB_NAME = "librt_reptext_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 RT_GEMM_MAX_GROUPS = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -43,6 +43,10 @@ class GemmGroup(C.Structure):
         ("alpha", C.c_float),
         ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
         ("stride_rowscale", C.c_int64),
+        ("a_bscale", C.c_void_p), ("a_bscale_plane", C.c_int64), ("a_bscale_rows", C.c_int64),
+        ("c8", C.c_void_p), ("c_bscale", C.c_void_p),
+        ("ldc8", C.c_int64), ("stride_c8", C.c_int64), ("c_bscale_plane", C.c_int64), ("c_bscale_rows", C.c_int64),
+        ("c8_from", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -55,6 +59,7 @@ SIGNATURES = {
     "rt_gemm_fp8": [C.POINTER(GemmGroup), _i32, _vp],
     "rt_gemm_tile_mode": [_i32],
     "rt_quantize_rows_fp8": [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _vp],
+    "rt_quantize_mx_fp8": [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     "rt_layernorm_modulate_fp8": [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_gemv_bf16w": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "rt_timestep_embedding": [_vp, _vp, _i32, _i32, _vp],
@@ -67,6 +72,7 @@ SIGNATURES = {
     "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
     "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fp8_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_attention_fp8_fwd_mx": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
     "rt_embedding_gather": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "rt_rmsnorm_rows": [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "rt_softmax_rows_bias": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],

@@ -54,6 +54,44 @@ def _batched(t: torch.Tensor, name: str):
 
 
 @dataclass
+class BlockScales:
+    """E8M0 block scales of an e4m3 activation tensor [B, R, D] (one byte per 32 consecutive elements of a row) in rt_gemm_group's
+    plane layout: ``t`` uint8 [D/256, B*R, 8] contiguous; byte (b, r, k) at t[k // 256, b*R + r, (k % 256) // 32]. ``rows(r0)`` /
+    ``cols(k0)`` address a sub-view of the e4m3 tensor (rows r0.. of every batch entry, columns k0.. with k0 % 256 == 0)."""
+
+    t: torch.Tensor
+    R: int
+    row0: int = 0
+    k0: int = 0
+
+    @staticmethod
+    def empty(B: int, R: int, D: int, device) -> "BlockScales":
+        if D % 256:
+            raise ValueError("block-scaled rows need D % 256 == 0")
+        return BlockScales(torch.empty(D // 256, B * R, 8, device=device, dtype=torch.uint8), R)
+
+    @property
+    def plane(self) -> int:
+        return self.t.stride(0)
+
+    def rows(self, r0: int) -> "BlockScales":
+        return BlockScales(self.t, self.R, self.row0 + r0, self.k0)
+
+    def cols(self, k0: int) -> "BlockScales":
+        if k0 % 256:
+            raise ValueError("column offset of block scales must be a multiple of 256")
+        return BlockScales(self.t, self.R, self.row0, self.k0 + k0)
+
+    def ptr(self) -> int:
+        if not self.t.is_cuda or self.t.dtype != torch.uint8 or not self.t.is_contiguous():
+            raise TypeError("block scales must be a contiguous uint8 tensor on the GPU")
+        return self.t.data_ptr() + (self.k0 // 256) * self.plane + self.row0 * 8
+
+    def planes_left(self) -> int:
+        return self.t.shape[0] - self.k0 // 256
+
+
+@dataclass
 class LinearProblem:
     """One group of rt_gemm_bf16: out = epilogue(a @ w.T + bias).
 
@@ -76,6 +114,12 @@ class LinearProblem:
     # fp8 problems (rt_gemm_fp8): a and w are float8_e4m3fn, a_scale f32 [B*M] (one per activation row), w_scale f32 [N]
     a_scale: Optional[torch.Tensor] = None
     w_scale: Optional[torch.Tensor] = None
+    # MX block scales (fp8 problems): a_bscale = the block scales of a; out8 / out8_scales = e4m3 + block-scale output for the
+    # columns >= out8_from (those columns are then not written to out): the next projection's operand, no pass in between
+    a_bscale: Optional[BlockScales] = None
+    out8: Optional[torch.Tensor] = None
+    out8_scales: Optional[BlockScales] = None
+    out8_from: int = 0
 
     @property
     def is_fp8(self) -> bool:
@@ -100,8 +144,18 @@ class LinearProblem:
                 if self.w_scale.numel() != N or not self.w_scale.is_contiguous():
                     raise ValueError("w_scale must be contiguous with N elements")
                 g.w_scale = _dev(self.w_scale, "w_scale", F32)
-        elif self.a_scale is not None or self.w_scale is not None:
-            raise TypeError("a_scale / w_scale belong to fp8 problems")
+            if self.a_bscale is not None:
+                if K % 256 or self.a_bscale.planes_left() < K // 256:
+                    raise ValueError("block-scaled a: K % 256 == 0 and one scale plane per 256 columns")
+                g.a_bscale, g.a_bscale_plane, g.a_bscale_rows = self.a_bscale.ptr(), self.a_bscale.plane, self.a_bscale.R
+            if self.out8 is not None:
+                B8, M8, N8, ld8, s8 = _batched(self.out8, "out8")
+                if self.out8_scales is None or (B8, M8) != (Bt, M) or N8 != N - self.out8_from or self.out8_scales.planes_left() < (N8 + 255) // 256:
+                    raise ValueError("out8 must be [.., M, N - out8_from] e4m3 with its block scales")
+                g.c8, g.c_bscale = _dev(self.out8, "out8", FP8), self.out8_scales.ptr()
+                g.ldc8, g.stride_c8, g.c_bscale_plane, g.c_bscale_rows, g.c8_from = ld8, s8, self.out8_scales.plane, self.out8_scales.R, int(self.out8_from)
+        elif self.a_scale is not None or self.w_scale is not None or self.a_bscale is not None or self.out8 is not None:
+            raise TypeError("a_scale / w_scale / block scales belong to fp8 problems")
         if self.out.dtype not in (BF16, F32):
             raise TypeError("out must be bf16 or f32")
         g.C = _dev(self.out, "out")
@@ -273,6 +327,33 @@ def quantize_rows_fp8_into(x: torch.Tensor, out: torch.Tensor, scale: torch.Tens
             scale.data_ptr() + b * R * 4, R, D, st))
 
 
+def quantize_mx_fp8_into(x: torch.Tensor, out: torch.Tensor, scales: BlockScales) -> None:
+    """x [B,R,D] bf16|f32 view -> out [B,R,D] e4m3 view + E8M0 block scales (one per 32 elements, rt_quantize_mx_fp8): the A operand
+    and a_bscale of an fp8 LinearProblem for tensors no fused producer writes."""
+    if x.dim() != 3 or out.dim() != 3 or x.shape != out.shape or x.stride(2) != 1 or out.stride(2) != 1:
+        raise ValueError("quantize_mx_fp8_into: x/out must be [B,R,D] views with unit inner stride")
+    B, R, D = x.shape
+    if x.dtype not in (BF16, F32):
+        raise TypeError("x must be bf16 or f32")
+    if D % 256 or scales.planes_left() < D // 256:
+        raise ValueError("D % 256 == 0 and one scale plane per 256 columns")
+    lib, st = native.load(), _stream()
+    esz = x.element_size()
+    _dev(out, "out", FP8), _dev(x, "x")
+    for b in range(B):
+        native.check("rt_quantize_mx_fp8", lib.rt_quantize_mx_fp8(
+            x.data_ptr() + b * x.stride(0) * esz, x.stride(1), int(x.dtype == F32), out.data_ptr() + b * out.stride(0), out.stride(1),
+            scales.ptr() + b * scales.R * 8, scales.plane, R, D, st))
+
+
+def dequantize_mx(q: torch.Tensor, scales: BlockScales) -> torch.Tensor:
+    """fp32 [B,R,D] value of an e4m3 tensor with block scales (host-side helper for tests and tools; torch ops)."""
+    B, R, D = q.shape
+    t = scales.t[scales.k0 // 256 : scales.k0 // 256 + D // 256].view(D // 256, -1, scales.R, 8)[:, :B, scales.row0 : scales.row0 + R]   # [D/256, B, R, 8]
+    e = t.permute(1, 2, 0, 3).reshape(B, R, D // 32).to(torch.float32) - 127.0
+    return (q.to(torch.float32).view(B, R, D // 32, 32) * torch.exp2(e).unsqueeze(-1)).view(B, R, D)
+
+
 def qk_rmsnorm_rope(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_txt, wk_txt, wq_img, wk_img,
                     cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6) -> None:
     """In place on buf [B,S,ld] bf16: heads at columns q_off + h*128 / k_off + h*128."""
@@ -359,6 +440,20 @@ def attention_fp8(qk8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, H: in
         _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), _dev(out, "out", BF16), out.stride(1), out.stride(0), B, S, H,
         float(scale if scale is not None else 128 ** -0.5), _stream()))
     return out
+
+
+def attention_fp8_mx(qk8: torch.Tensor, vt8: torch.Tensor, out8: torch.Tensor, scales: BlockScales, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    """attention_fp8 with the output as e4m3 + E8M0 block scales (rt_attention_fp8_fwd_mx): out8 [B,S,>=H*128] e4m3 view, head h at
+    columns h*128.. of the view; ``scales`` addresses the same view."""
+    B, S, _ = qk8.shape
+    if out8.dim() != 3 or out8.shape[0] != B or out8.shape[1] != S or out8.stride(2) != 1:
+        raise ValueError("out8 must be [B,S,*] with unit inner stride")
+    if scales.planes_left() < (H * 128) // 256:
+        raise ValueError("one scale plane per 256 output columns")
+    native.check("rt_attention_fp8_fwd_mx", native.load().rt_attention_fp8_fwd_mx(
+        _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), _dev(out8, "out8", FP8), out8.stride(1), out8.stride(0), scales.ptr(), scales.plane, scales.R,
+        B, S, H, float(scale if scale is not None else 128 ** -0.5), _stream()))
+    return out8
 
 
 def euler_step_(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> torch.Tensor:

@@ -78,6 +78,22 @@ typedef struct rt_gemm_group {
   const float* w_scale; /* f32 [N], one per output channel (rt_quantize_rows_fp8 on the weight rows)              */
   int64_t stride_rowscale; /* elements between the rowscale vectors of consecutive batch entries; 0 = one vector shared by the
                             * batch (the reference's one mask per text line); > 0: a mask per image of a sharded batch        */
+  /* MX block scales (ABI 8; rt_gemm_fp8 only, ignored by rt_gemm_bf16). An activation row carries one E8M0 byte s (value
+   * 2^(s-127)) per 32 consecutive K-elements, kept in planes of 256 K-elements so that the 256 rows x 8 bytes a GEMM tile needs
+   * per two K-tiles are one contiguous 2-KiB piece:   byte(b, m, k) = base + (k/256)*plane + (b*rows + m)*8 + (k%256)/32.
+   *  a_bscale != NULL: A's block scales, applied by the MFMA itself (v_mfma_scale_f32_16x16x128_f8f6f4's scale operand) before
+   *    the fp32 accumulation; K % 256 == 0; a_scale may be NULL (usual) or given as well.
+   *  c8 != NULL: columns n >= c8_from are NOT written to C; the epilogue value v (after every term) is quantised per 32 columns —
+   *    s = the smallest exponent byte with max|v| <= 448 * 2^(s-127) (rt_quantize_mx_fp8's rule) — and stored as
+   *    e4m3(v * 2^(127-s)) at c8[b*stride_c8 + m*ldc8 + (n - c8_from)] with s at the byte the layout above gives for
+   *    k = n - c8_from under (c_bscale, c_bscale_plane, c_bscale_rows): the next GEMM's A and a_bscale, with no pass in between.
+   *    c8_from % 256 == 0, (N - c8_from) % 32 == 0, ldc8 % 8 == 0, c8 8-byte aligned. */
+  const uint8_t* a_bscale;
+  int64_t a_bscale_plane, a_bscale_rows;
+  uint8_t* c8;
+  uint8_t* c_bscale;
+  int64_t ldc8, stride_c8, c_bscale_plane, c_bscale_rows;
+  int32_t c8_from, reserved0;
 } rt_gemm_group;
 
 int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
@@ -100,6 +116,14 @@ int rt_gemm_fp8(const rt_gemm_group* groups /* host */, int32_t ngroups, void* s
  * output channels) and for activation rows that do not come out of a LayerNorm. */
 int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, float* scale,
                          int32_t rows, int32_t D, void* stream);
+
+/* MX block quantisation of activation rows (config 5, "mx" level): per 32 consecutive elements one E8M0 scale byte
+ * s = the smallest with max|x| <= 448 * 2^(s-127), clamped to [1, 253]; out = e4m3(x * 2^(127-s)), round to nearest even.
+ * x bf16 (x_f32 = 0) or f32 [rows][ldx]; out bytes [rows][ldo]; scales in rt_gemm_group's plane layout
+ * (bscale + (k/256)*plane + row*8 + (k%256)/32). D % 256 == 0. The fused producers (rt_gemm_fp8's c8 output,
+ * rt_attention_fp8_fwd_mx) apply the same rule to their fp32 results; this pass serves tensors no fused producer writes. */
+int rt_quantize_mx_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, uint8_t* bscale, int64_t plane,
+                       int32_t rows, int32_t D, void* stream);
 
 /* Small-M linear on fp32 activations, bf16 weights (adaLN modulation, time/guidance/pooled MLPs):
  *   y[b][n] (+)= post( Σ_k pre(x[b][k]) · W[n][k] + bias[n] ),  pre/post ∈ {identity, SiLU}
@@ -181,6 +205,13 @@ int rt_attention_fp8_prep(const void* buf, int64_t ld, int64_t stride_b, int64_t
                           int32_t B, int32_t S, int32_t T, int32_t H, float eps, void* stream);
 int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, int64_t ldo, int64_t stride_ob,
                          int32_t B, int32_t S, int32_t H, float scale, void* stream);
+/* The same attention with the output written as the NEXT projection's e4m3 A operand (config 5, "mx" level): o8[b][q][h*128 + d]
+ * = e4m3(o * 2^(127-s)) with one E8M0 byte s per (row, 32 columns) in rt_gemm_group's plane layout (rt_quantize_mx_fp8's rule
+ * applied to the fp32 output; no bf16 store and no quantisation pass in between): bscale + ((h*128 + d)/256)*plane +
+ * (b*bscale_rows + q)*8 + ((h*128 + d)%256)/32. H even. Replaces `F.scaled_dot_product_attention` + the operand cast of to_out /
+ * proj_out (A.1 steps 6-7, A.2) on the e4m3 path. */
+int rt_attention_fp8_fwd_mx(const void* qk8, const void* vt8, void* o8, int64_t ldo8, int64_t stride_ob8, uint8_t* bscale,
+                            int64_t plane, int64_t bscale_rows, int32_t B, int32_t S, int32_t H, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Prompt encoders (PIPE:232-347: T5-XXL encoder -> prompt_embeds [B,512,4096], CLIP-L text model ->

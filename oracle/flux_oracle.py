@@ -76,7 +76,10 @@ _FP8_SUFFIXES_ALL = _FP8_SUFFIXES + (".attn.to_out.0", ".attn.to_add_out", ".ff.
 
 @contextlib.contextmanager
 def fp8_linears(on=True):
-    """on: True / "ln" = the LayerNorm-fed projections, "all" = every projection inside the blocks."""
+    """on: True / "ln" = the LayerNorm-fed projections, "all" = every projection inside the blocks (per-row scales), "mx" = every
+    projection, the ones NOT fed by a LayerNorm (to_out, to_add_out, ff.net.2, ff_context.net.2, proj_out) with one E8M0 scale per
+    32 consecutive input elements (`quant_mx_e4m3`) taken from the fp32 value their producer computed (GELU hidden, e4m3 attention
+    output: no bf16 store in between — csrc/gemm_bf16.hip's c8 epilogue, rt_attention_fp8_fwd_mx)."""
     global _FP8
     prev, _FP8 = _FP8, ("ln" if on is True else on)
     try:
@@ -93,6 +96,31 @@ def quant_rows_e4m3(x: torch.Tensor) -> torch.Tensor:
     return q * sc
 
 
+def mx_scale_byte(amax: torch.Tensor) -> torch.Tensor:
+    """E8M0 byte of a block with maximum magnitude amax (csrc/rt_common.h: rt_mx_scale_byte): the smallest s with
+    amax <= 448 * 2^(s-127), from the float's own exponent and mantissa; clamped to [1, 253]; 1 for an all-zero block."""
+    m, e = torch.frexp(amax.to(torch.float32))                    # amax = m * 2^e, m in [0.5, 1)  ->  (2m) * 2^(e-1)
+    s = e.to(torch.int32) - 1 + 127 - 8 + (2.0 * m > 1.75).to(torch.int32)
+    s = torch.where(amax > 0, s, torch.ones_like(s))
+    return s.clamp(1, 253)
+
+
+def quant_mx_e4m3(x: torch.Tensor, return_parts: bool = False):
+    """Quantise-dequantise along the last dim in blocks of 32 with a power-of-two scale per block (rt_quantize_mx_fp8)."""
+    shp = x.shape
+    xb = x.to(torch.float32).reshape(*shp[:-1], shp[-1] // 32, 32)
+    sb = mx_scale_byte(xb.abs().amax(dim=-1))
+    q = torch.ldexp(xb, (127 - sb).unsqueeze(-1)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    if return_parts:
+        return q.reshape(shp), sb.to(torch.uint8)
+    return torch.ldexp(q.to(torch.float32), (sb - 127).unsqueeze(-1)).reshape(shp)
+
+
+def _act_out(x: torch.Tensor) -> torch.Tensor:
+    """Output of a producer the "mx" level fuses its quantisation into: not stored as bf16 there."""
+    return x if _FP8 == "mx" else _s(x)
+
+
 def _ln_out(x: torch.Tensor) -> torch.Tensor:
     """LayerNorm-modulate output: stored as bf16 on the bf16 path, quantised straight from fp32 on the fp8 path."""
     return x if _FP8 else _s(x)
@@ -101,7 +129,9 @@ def _ln_out(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------- primitives
 def linear(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
     w = p[name + ".weight"]
-    if _FP8 and "transformer_blocks." in name and name.endswith(_FP8_SUFFIXES_ALL if _FP8 == "all" else _FP8_SUFFIXES):
+    if _FP8 and "transformer_blocks." in name and name.endswith(_FP8_SUFFIXES_ALL if _FP8 in ("all", "mx") else _FP8_SUFFIXES):
+        if _FP8 == "mx" and not name.endswith(_FP8_SUFFIXES):
+            return F.linear(quant_mx_e4m3(x), quant_rows_e4m3(w), p.get(name + ".bias"))
         return F.linear(quant_rows_e4m3(x), quant_rows_e4m3(w), p.get(name + ".bias"))
     return F.linear(x, w, p.get(name + ".bias"))
 
@@ -192,7 +222,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor
         s = (_e4m3(qh * 16.0) @ _e4m3(kh * 16.0).transpose(-1, -2)) * (1.0 / (256.0 * math.sqrt(Dh)))
         e = torch.exp2((s - s.amax(dim=-1, keepdim=True)) * math.log2(math.e) + 2.0)
         o = (_e4m3(e) @ _e4m3(vh)) / e.sum(dim=-1, keepdim=True)
-        return _s(o.permute(0, 2, 1, 3).reshape(B, S, H * Dh))
+        return _act_out(o.permute(0, 2, 1, 3).reshape(B, S, H * Dh))
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(Dh)
     if _STORE is None:
         o = torch.softmax(s, dim=-1) @ vh
@@ -230,7 +260,7 @@ def double_block(p: Params, pre: str, h, e, temb, rope, H: int = 24, Dh: int = 1
     a_h = linear(p, f"{pre}.attn.to_out.0", A[:, T:])
 
     def ff(name, x):
-        return linear(p, f"{pre}.{name}.net.2", _s(gelu_tanh(linear(p, f"{pre}.{name}.net.0.proj", x))))
+        return linear(p, f"{pre}.{name}.net.2", _act_out(gelu_tanh(linear(p, f"{pre}.{name}.net.0.proj", x))))
 
     h = h + g_a[:, None] * a_h
     h = h + g_m[:, None] * ff("ff", _ln_out(layer_norm(h) * (1 + sc_m[:, None]) + sh_m[:, None]))
@@ -245,7 +275,7 @@ def single_block(p: Params, pre: str, x, temb, rope, H: int = 24, Dh: int = 128)
     cos, sin = rope
     sh, sc, g = linear(p, f"{pre}.norm.linear", silu(temb)).chunk(3, dim=-1)
     nx = _ln_out(layer_norm(x) * (1 + sc[:, None]) + sh[:, None])
-    m = _s(gelu_tanh(linear(p, f"{pre}.proj_mlp", nx)))
+    m = _act_out(gelu_tanh(linear(p, f"{pre}.proj_mlp", nx)))
     q = rms_norm(_s(linear(p, f"{pre}.attn.to_q", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_q.weight"])
     k = rms_norm(_s(linear(p, f"{pre}.attn.to_k", nx)).reshape(B, S, H, Dh), p[f"{pre}.attn.norm_k.weight"])
     v = _s(linear(p, f"{pre}.attn.to_v", nx)).reshape(B, S, H, Dh)
