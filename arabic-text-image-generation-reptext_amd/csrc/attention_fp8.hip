@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void prep_vt_kernel(const bf16_t* __restrict__
 __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t* __restrict__ qk8, const uint8_t* __restrict__ vt8,
                                                                    bf16_t* O, int64_t ldo, int64_t stride_ob, int S, int S64, int H,
                                                                    float scale_log2, uint8_t* O8, int64_t ldo8, int64_t stride_ob8,
-                                                                   uint8_t* bsc, int64_t bsc_plane, int64_t bsc_rows) {
+                                                                   uint8_t* bsc, int64_t bsc_plane, int64_t bsc_rows, int bsc_k0) {
   __shared__ __attribute__((aligned(16))) char smem[2 * SLOT_B];   // [slot][K 8 KiB | Vᵀ 8 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -355,8 +355,11 @@ __global__ __launch_bounds__(THREADS, 2) void attention_fp8_kernel(const uint8_t
         if (valid) *reinterpret_cast<u32x2*>(orow + dt * 32 + 8 * (g + hh)) = u32x2{x[0], x[1]};
       }
     }
-    if (valid && hh == 0)
-      *reinterpret_cast<uint32_t*>(bsc + (int64_t)(head >> 1) * bsc_plane + ((int64_t)b * bsc_rows + m) * 8 + (head & 1) * 4) = sbytes;
+    if (valid && hh == 0) {
+      const int64_t o0 = rt_mx_scale_offset((int64_t)b * bsc_rows + m, bsc_k0 + head * DH, bsc_plane);      // block dt of the head: 4 bytes further each
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) bsc[o0 + 4 * dt] = (uint8_t)(sbytes >> (8 * dt));
+    }
     return;
   }
   const bool wide = (ldo % 8 == 0) && (stride_ob % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
@@ -415,22 +418,25 @@ extern "C" int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, i
   const dim3 grid(8 * ((NI + 7) / 8), B);
   hipLaunchKernelGGL(attention_fp8_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream, (const uint8_t*)qk8, (const uint8_t*)vt8,
                      (bf16_t*)o, ldo, stride_ob, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE), (uint8_t*)nullptr,
-                     (int64_t)0, (int64_t)0, (uint8_t*)nullptr, (int64_t)0, (int64_t)0);
+                     (int64_t)0, (int64_t)0, (uint8_t*)nullptr, (int64_t)0, (int64_t)0, 0);
   return rt_hip_status();
 }
 
 extern "C" int rt_attention_fp8_fwd_mx(const void* qk8, const void* vt8, void* o8, int64_t ldo8, int64_t stride_ob8, uint8_t* bscale,
-                                       int64_t plane, int64_t bscale_rows, int32_t B, int32_t S, int32_t H, float scale, void* stream) {
+                                       int64_t plane, int64_t bscale_rows, int32_t bscale_k0, int32_t B, int32_t S, int32_t H, float scale,
+                                       void* stream) {
   if (!qk8 || !vt8 || !o8 || !bscale || B < 1 || S < 1 || H < 1) return RT_E_BADARG;
-  if (!RT_ALIGNED(qk8, 16) || !RT_ALIGNED(vt8, 16) || !RT_ALIGNED(o8, 8) || ldo8 % 8 || stride_ob8 % 8 || !RT_ALIGNED(bscale, 4) || plane % 8)
+  if (!RT_ALIGNED(qk8, 16) || !RT_ALIGNED(vt8, 16) || !RT_ALIGNED(o8, 8) || ldo8 % 8 || stride_ob8 % 8 || !RT_ALIGNED(bscale, 16) || plane % 2048)
     return RT_E_ALIGN;
-  if (ldo8 < (int64_t)H * DH || H % 2 != 0 || plane < ((int64_t)(B - 1) * bscale_rows + S) * 8) return RT_E_SHAPE;
+  if (ldo8 < (int64_t)H * DH || bscale_k0 < 0 || bscale_k0 % 128 != 0 || bscale_rows % 64 != 0 ||
+      plane < ((((int64_t)(B - 1) * bscale_rows + S) + 63) / 64) * 2048)
+    return RT_E_SHAPE;
   if ((int64_t)(S + BKV) * 2 * H * DH >= (int64_t)1 << 31) return RT_E_SHAPE;
   const int S64 = (S + BKV - 1) / BKV * BKV;
   const int NI = H * ((S + BQ - 1) / BQ);
   const dim3 grid(8 * ((NI + 7) / 8), B);
   hipLaunchKernelGGL(attention_fp8_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream, (const uint8_t*)qk8, (const uint8_t*)vt8,
                      (bf16_t*)nullptr, (int64_t)0, (int64_t)0, S, S64, H, scale * 1.4426950408889634f / (QK_PRESCALE * QK_PRESCALE), (uint8_t*)o8,
-                     ldo8, stride_ob8, bscale, plane, bscale_rows);
+                     ldo8, stride_ob8, bscale, plane, bscale_rows, (int)bscale_k0);
   return rt_hip_status();
 }

@@ -122,6 +122,7 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
     }
   };
   if (g.res || g.add2) fetch_row(0);
+  uint32_t sbw[(NJ + 1) / 2] = {};                     // MX output: scale bytes of four consecutive fragment rows per 32-column block
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int m = mrow + 16 * i;
@@ -202,9 +203,17 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
           const int k8 = n8 - g.c8_from;                                             // column of the consumer's A
           if (m < g.M && n8 < g.N)
             *reinterpret_cast<u32x2*>(g.c8 + (int64_t)bidx * g.stride_c8 + (int64_t)m * g.ldc8 + k8) = u32x2{x[0], x[1]};
-          const int kb = (ncol - 4 * c) + 16 * jp - g.c8_from;                       // first column of the block
-          if (c == 0 && m < g.M && kb + g.c8_from < g.N)
-            g.c_bscale[(int64_t)(kb >> 8) * g.c_bscale_plane + ((int64_t)bidx * g.c_bscale_rows + m) * 8 + ((kb & 255) >> 5)] = (uint8_t)sb;
+          // scale bytes: in rt_mx_scale_offset's order the rows m, m+16, m+32, m+48 of a 64-row chunk (the four fragment rows of an
+          // a-half of this lane) are consecutive bytes: gathered over four passes of the row loop and stored as ONE dword. Rows past M
+          // inside the chunk get whatever their accumulators hold — padding rows of the scale tensor, never read for a stored result.
+          sbw[jp >> 1] |= (uint32_t)sb << (8 * (i & 3));
+          if ((i & 3) == 3) {
+            const int kb = (ncol - 4 * c) + 16 * jp - g.c8_from;                     // first column of the block
+            const int m4 = m - 48;                                                   // first of the four rows
+            if (c == 0 && m4 < g.M && kb + g.c8_from < g.N)
+              *reinterpret_cast<uint32_t*>(g.c_bscale + rt_mx_scale_offset((int64_t)bidx * g.c_bscale_rows + m4, kb + g.c_bscale_k0, g.c_bscale_plane)) = sbw[jp >> 1];
+            sbw[jp >> 1] = 0;
+          }
         }
       }
     }
@@ -274,11 +283,15 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 //              the chunks the bf16 form reads for its k-steps 0 and 1 — for both operands alike, so the contraction still
 //              covers every k exactly once and the reads keep their conflict-free pattern.
 //
-// MX = true (e4m3 only): A carries one E8M0 block scale per 32 K-elements (rt_gemm_group::a_bscale). The 256 rows x 8 bytes a tile
-//              needs per PAIR of K-tiles are one contiguous 2-KiB run of the scale plane: every wave fetches 256 B of it with one 4-byte
-//              LDS-DMA piece, issued together with part a0 of every EVEN K-tile (so it is retired by the waits that retire a0)
-//              into a 2 x 2 KiB ring behind the operand buffers. A lane reads the byte of its (row, 32-element block) with one
-//              ds_read_u8 per fragment next to the fragment itself and hands it to the MFMA as the scale of its second operand
+// MX = true (e4m3 only): A carries one E8M0 block scale per 32 K-elements (rt_gemm_group::a_bscale). The 256 rows x 4 bytes a tile
+//              needs per K-tile make 8 KiB per EIGHT K-tiles: every wave fetches one contiguous 1-KiB run of the scale plane (four
+//              K-tiles of a 64-row chunk, rt_mx_scale_offset's order) with one 16-byte LDS-DMA piece, issued together with part a0 of
+//              every eighth K-tile (so it is retired by the waits that retire a0) into a 2 x 8 KiB ring behind the operand buffers
+//              (a 4-byte piece per pair of K-tiles cost 4.5 % at K = 15360: an LDS-DMA holds its wave's issue whatever its size; one
+//              per eight K-tiles is a quarter of that). The chunk order
+//              puts the scales of the four fragment rows of an a-half that a lane feeds with its K-block j into ONE dword: a lane
+//              reads it with one ds_read_b32 per a-half and K-tile and the MFMA picks the fragment's byte by its op_sel immediate
+//              (8 ds_read_u8 per K-tile instead cost +6 % at K = 15360, tools/mx_dev). The scale goes to the MFMA's second operand
 //              (the activation rows; the weights keep scale 2^0). Measured (tools/mx_dev/probe_scales.py): in the instruction's own
 //              K order lane group g holds k = 16g..16g+15 in its first four registers and 64+16g.. in the other four — the chunks
 //              j and j+4 read above, so the hardware's K order IS the memory order — and the byte supplied by lane group b scales
@@ -355,18 +368,29 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
       __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
                                                (int)src[first + q], koff, 0, 0);
   };
-  // MX: the scale piece of K-tile pair `pair` -> ring slot pair & 1. Lane l of wave w covers row 32w + l/2, K-tile l & 1 of the pair.
+  // MX: the scale piece of K-tile octet `oct` -> ring slot oct & 1. Wave w copies 1 KiB: 64-row chunk w & 3 of the tile, K-tiles
+  // 4(w >> 2) .. +3 of the octet (LDS image [w][K-tile & 3][256 B]); chunks past the last row are clamped (their rows are never stored).
   constexpr int SC_OFF = 2 * T::BUF_BYTES;
-  __amdgpu_buffer_rsrc_t rsrcS;
-  int sc_src = 0;
+  // The base pointer and the plane size are detached from the kernel-argument struct by an opaque asm: otherwise hipcc, short of
+  // SGPRs in this loop, re-materialises them from the spilled struct — 16 v_readlane_b32 in every odd K-tile (+9 % at K = 15360).
+  uint32_t sc_lo = 0, sc_hi = 0;
+  int sc_plane = 0, sc_src = 0;
   if constexpr (MX) {
-    rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.a_bscale), 0, -1, 0x00020000);
-    const int row = wave * 32 + (lane >> 1);
-    sc_src = (int)(((int64_t)bidx * g.a_bscale_rows + min(m0 + row, g.M - 1)) * 8 + (lane & 1) * 4);
+    static_assert(T::BM == 256 && T::NI0 == 4 && T::NI1 == 4, "the scale chunk order is that of the 256-row tile");
+    sc_lo = (uint32_t)reinterpret_cast<uintptr_t>(g.a_bscale);
+    sc_hi = (uint32_t)(reinterpret_cast<uintptr_t>(g.a_bscale) >> 32);
+    sc_plane = (int)g.a_bscale_plane;
+    asm volatile("" : "+s"(sc_lo), "+s"(sc_hi), "+s"(sc_plane));
+    const int64_t row_b = (int64_t)bidx * g.a_bscale_rows;             // multiple of 64 (host check), m0 is a multiple of 256
+    const int chunk = (int)min((row_b + m0) / 64 + (wave & 3), (row_b + g.M - 1) / 64);
+    sc_src = chunk * 2048 + (wave >> 2) * 1024 + lane * 16;
   }
-  auto issue_scales = [&](int pair) {
-    if constexpr (MX)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, LDS_PTR(smem + SC_OFF + (pair & 1) * 2048 + wave * 256), 4, sc_src, pair * (int)g.a_bscale_plane, 0, 0);
+  auto issue_scales = [&](int oct) {
+    if constexpr (MX) {
+      const __amdgpu_buffer_rsrc_t rsrcS =
+          __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(((uint64_t)sc_hi << 32) | sc_lo), 0, -1, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, LDS_PTR(smem + SC_OFF + (oct & 1) * 8192 + wave * 1024), 16, sc_src, oct * sc_plane, 0, 0);
+    }
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
@@ -377,7 +401,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   const int sw = (lane >> 1) & 7;
   const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
-  const int sc_rd = SC_OFF + (wm * T::WMR + l15) * 8 + (lane >> 4);         // MX: + slot*2048 + fragment*128 + (K-tile & 1)*4
+  const int sc_rd = SC_OFF + wm * 2048 + l15 * 16 + (lane >> 4) * 4;         // MX: + slot*8192 + (K-tile & 4)*1024 + a-half*1024 + (K-tile & 3)*256
   const int a_base = wm * T::WMR * 128;
   const int w_base = T::A_BYTES + wn * T::WNC * 128;
 
@@ -388,9 +412,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     for (int j = 0; j < T::NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[T::NIH][2];        // current a-half: [frag][kk]
   bf16x8 wf[2][T::NJH][2];     // both b-halves: [half][frag][kk]
-  int sc[T::NIH];              // MX: block scale byte of the current a-half's fragments for this K-tile
-#pragma unroll
-  for (int i = 0; i < T::NIH; ++i) sc[i] = 0x7F;
+  int sc = 0x7F7F7F7F;         // MX: block scale bytes of the current a-half's four fragments (byte i = fragment i) for this K-tile
 
 #define RT_NIH(ah) ((ah) ? T::NI1 : T::NI0)
 #define RT_NJH(bh) ((bh) ? T::NJ1 : T::NJ0)
@@ -400,25 +422,26 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd1);                     \
   }
 #define RT_READ_S(ah, kt_)                                                                                        \
-  if constexpr (MX) {                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                        \
-      sc[i] = *reinterpret_cast<const uint8_t*>(smem + sc_rd + (((kt_) >> 1) & 1) * 2048 + ((ah)*T::NI0 + i) * 128 + ((kt_) & 1) * 4); \
-  }
+  if constexpr (MX) sc = *reinterpret_cast<const int*>(smem + sc_rd + (((kt_) >> 3) & 1) * 8192 + ((kt_) & 4) * 1024 + (ah)*1024 + ((kt_) & 3) * 256);
 #define RT_READ_B(bh)                                                                                             \
   _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j) {                                                        \
     wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*T::NJ0 + j) * 2048 + rd0);                 \
     wf[bh][j][1] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*T::NJ0 + j) * 2048 + rd1);                 \
   }
 #define RT_CAT8(lo, hi) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7)
+/* one fragment row i of the quadrant; i is a literal: the scale byte of fragment i is picked by the op_sel IMMEDIATE */ \
+#define RT_MFMA8_ROW(ah, bh, i)                                                                                   \
+  if constexpr ((i) < RT_NIH(ah)) {                                                                               \
+    _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j)                                                        \
+      acc[(ah)*T::NI0 + (i)][(bh)*T::NJ0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                 \
+          RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*T::NI0 + (i)][(bh)*T::NJ0 + j], \
+          0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* weights: 2^0 */, MX ? ((i) & 3) : 0, MX ? sc : 0x7F7F7F7F); \
+  }
 #define RT_MFMA(ah, bh)                                                                                           \
   do {                                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     if constexpr (FP8) {                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                      \
-        _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j)                                                    \
-          acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
-              RT_CAT8(wf[bh][j][0], wf[bh][j][1]), RT_CAT8(af[i][0], af[i][1]), acc[(ah)*T::NI0 + i][(bh)*T::NJ0 + j], \
-              0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F /* weights: 2^0 */, 0, MX ? sc[i] : 0x7F7F7F7F);     \
+      RT_MFMA8_ROW(ah, bh, 0); RT_MFMA8_ROW(ah, bh, 1); RT_MFMA8_ROW(ah, bh, 2); RT_MFMA8_ROW(ah, bh, 3); RT_MFMA8_ROW(ah, bh, 4); \
     } else {                                                                                                      \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                            \
         _Pragma("unroll") for (int i = 0; i < RT_NIH(ah); ++i)                                                    \
@@ -435,10 +458,11 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   RT_BAR();
   if (wm == 1) RT_BAR();                       // stagger waves 4-7 by one barrier
 
-  // MX: the scale piece of the NEXT pair of K-tiles goes out with part a0 of every even tile, i.e. in the odd iterations. The counted
-  // waits keep their immediates: with the extra piece among the younger ones they ask for one more of the older pieces (issued a
-  // phase earlier) than strictly needed — conservative, never too weak. (Unrolling the loop by two to give the odd iterations their
-  // own immediates cost 18 spilled VGPRs: the compiler then keeps both buffers' address sets live.)
+  // MX: the scale piece of the NEXT eight K-tiles goes out with part a0 of every eighth tile, i.e. in iterations kt % 8 == 7. The counted
+  // waits keep their immediates: with the extra piece among the younger ones they ask for one more of the older pieces than strictly
+  // needed — conservative, never too weak. Measured alternatives (tools/mx_dev, K = 15360): exact immediates behind a scalar branch
+  // on kt & 1 are 4 % SLOWER (the branch splits the block between the DMA issue and the barrier); unrolling the loop by two to make
+  // the parity a compile-time fact costs 18 spilled VGPRs (both buffers' address sets stay live).
   for (int kt = 0; kt + 1 < nk; ++kt) {
     const char* tb = smem + (kt & 1) * T::BUF_BYTES;
     const int nb = (kt & 1) ^ 1;
@@ -446,7 +470,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     // ---- phase 1: (a0,b0)
     RT_READ_A(0); RT_READ_S(0, kt); RT_READ_B(0);
     issue(P0{}, nb, koff);
-    if constexpr (MX) { if (kt & 1) issue_scales((kt + 1) >> 1); }
+    if constexpr (MX) { if ((kt & 7) == 7) issue_scales((kt + 1) >> 3); }
     rt_vmcnt<T::PA1 + T::PA0>();               // b1(kt) landed (younger: a1(kt), a0(kt+1))
     RT_BAR(); RT_MFMA(0, 0); RT_BAR();
     // ---- phase 2: (a0,b1)
@@ -480,6 +504,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
 #undef RT_READ_B
 #undef RT_READ_S
 #undef RT_MFMA
+#undef RT_MFMA8_ROW
 #undef RT_CAT8
 #undef RT_NIH
 #undef RT_NJH
@@ -635,14 +660,16 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
       if ((g.a_bscale != nullptr) != (groups[0].a_bscale != nullptr)) return RT_E_BADARG;
       if (g.a_bscale) {
         mx = true;
-        if (g.K % 256 != 0 || g.a_bscale_plane % 8 != 0 || g.a_bscale_plane < (int64_t)g.M * 8) return RT_E_SHAPE;
-        if ((int64_t)(g.K / 256) * g.a_bscale_plane >= ((int64_t)1 << 31) || ((int64_t)g.batch * g.a_bscale_rows + g.M) * 8 >= ((int64_t)1 << 31)) return RT_E_SHAPE;
-        if (!RT_ALIGNED(g.a_bscale, 4)) return RT_E_ALIGN;
+        if (g.a_bscale_plane % 2048 != 0 || g.a_bscale_rows % 64 != 0) return RT_E_SHAPE;
+        if (g.a_bscale_plane < ((((int64_t)(g.batch - 1) * g.a_bscale_rows + g.M) + 63) / 64) * 2048) return RT_E_SHAPE;
+        if ((int64_t)((g.K + 1023) / 1024) * g.a_bscale_plane >= ((int64_t)1 << 31)) return RT_E_SHAPE;
+        if (!RT_ALIGNED(g.a_bscale, 16)) return RT_E_ALIGN;
       }
       if (g.c8) {
         if (g.out_f32 || !g.c_bscale) return RT_E_BADARG;
-        if (g.c8_from < 0 || g.c8_from % 256 != 0 || g.c8_from >= g.N || (g.N - g.c8_from) % 32 != 0 || g.c_bscale_plane % 8 != 0) return RT_E_SHAPE;
-        if (!RT_ALIGNED(g.c8, 8) || g.ldc8 % 8 || g.stride_c8 % 8) return RT_E_ALIGN;
+        if (g.c8_from < 0 || g.c8_from % 256 != 0 || g.c8_from >= g.N || (g.N - g.c8_from) % 32 != 0 || g.c_bscale_plane % 2048 != 0 || g.c_bscale_rows % 64 != 0 ||
+            g.c_bscale_k0 < 0 || g.c_bscale_k0 % 32 != 0) return RT_E_SHAPE;
+        if (!RT_ALIGNED(g.c8, 8) || g.ldc8 % 8 || g.stride_c8 % 8 || !RT_ALIGNED(g.c_bscale, 16)) return RT_E_ALIGN;
       }
     }
     L.grp[i].g = g;
@@ -656,7 +683,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   if (!attr_done) {
     int e = set_lds(gemm_pp_kernel<false, Geo256>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_pp_kernel<true, Geo256>, Geo256::LDS_BYTES);
-    if (!e) e = set_lds(gemm_pp_kernel<true, Geo256, true>, Geo256::LDS_BYTES + 4096);
+    if (!e) e = set_lds(gemm_pp_kernel<true, Geo256, true>, Geo256::LDS_BYTES + 16384);
     if (!e) e = set_lds(gemm_pp_kernel<false, Geo288>, Geo288::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo192>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo128>, Geo256::LDS_BYTES);
@@ -665,7 +692,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   }
   hipStream_t st = (hipStream_t)stream;
   if (fp8) {
-    if (mx) hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256, true>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES + 4096, st, L);
+    if (mx) hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256, true>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES + 16384, st, L);
     else hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
     return rt_hip_status();
   }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const void* __rest
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = fminf(fmaxf(y[i] * inv, -E4M3_MAX), E4M3_MAX);
   *reinterpret_cast<u32x2*>(out + (int64_t)row * ldo + col) = pack_e4m3x8(y);
-  if ((threadIdx.x & 3) == 0) bscale[(int64_t)(col >> 8) * plane + (int64_t)row * 8 + ((col & 255) >> 5)] = (uint8_t)sb;
+  if ((threadIdx.x & 3) == 0) bscale[rt_mx_scale_offset(row, col, plane)] = (uint8_t)sb;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -588,8 +588,8 @@ int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, i
 int rt_quantize_mx_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, uint8_t* bscale, int64_t plane,
                        int32_t rows, int32_t D, void* stream) {
   if (!x || !out || !bscale || rows < 1 || D < 256) return RT_E_BADARG;
-  if (D % 256 || plane < (int64_t)rows * 8) return RT_E_SHAPE;
-  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8) return RT_E_ALIGN;
+  if (D % 256 || plane % 2048 || plane < (((int64_t)rows + 63) / 64) * 2048) return RT_E_SHAPE;
+  if (!RT_ALIGNED(x, 16) || !RT_ALIGNED(out, 8) || ldx % 8 || ldo % 8 || !RT_ALIGNED(bscale, 16)) return RT_E_ALIGN;
   const int64_t n = (int64_t)rows * (D / 8);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;

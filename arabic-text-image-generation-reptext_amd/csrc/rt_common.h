@@ -129,6 +129,14 @@ __device__ __forceinline__ int rt_mx_scale_byte(float amax) {
 // 2^-(s-127) as a float, exact for s in [1, 253]
 __device__ __forceinline__ float rt_mx_inv_scale(int s) { return __uint_as_float((uint32_t)(254 - s) << 23); }
 
+// Byte offset of the scale of (row, k) inside a scale tensor (reptext_hip.h, rt_gemm_group): planes of 1024 K-elements (8 K-tiles of
+// 128); inside a plane 64-row chunks of 2 KiB ordered [K-tile][row & 15][32-block of the K-tile][row >> 4 & 3] — the order in which a
+// GEMM wave wants them: 1 KiB = what one wave copies per eight K-tiles (four K-tiles of one chunk), one dword = the four fragment
+// rows (16 apart) a lane feeds with the same K-block.
+__device__ __forceinline__ int64_t rt_mx_scale_offset(int64_t row, int k, int64_t plane) {
+  return (int64_t)(k >> 10) * plane + (row >> 6) * 2048 + ((k & 1023) >> 7) * 256 + (row & 15) * 16 + ((k & 127) >> 5) * 4 + ((row >> 4) & 3);
+}
+
 // max over the four lanes {l&15 + 16c, c = 0..3} (the 16-lane rows of a wave), result in all four: v_permlane16_swap exchanges the
 // odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half. Inline asm
 // for the reason given at the row-max exchange of attention.hip (hipcc folds max(result[0], result[1]) of the builtins).

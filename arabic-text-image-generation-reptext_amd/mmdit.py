@@ -93,6 +93,7 @@ class DoublePlan:
     ff2_txt_w8: Optional[torch.Tensor] = None
     ff2_txt_ws: Optional[torch.Tensor] = None
     fp8_attention: bool = False
+    mx: bool = False        # level "mx": those projections read e4m3 + E8M0 block scales written by the producing epilogue
 
 
 @dataclass
@@ -110,6 +111,7 @@ class SinglePlan:
     out_w8: Optional[torch.Tensor] = None
     out_ws: Optional[torch.Tensor] = None
     fp8_attention: bool = False
+    mx: bool = False
 
 
 def _fuse(lins) -> tuple:
@@ -127,7 +129,8 @@ def _fuse(lins) -> tuple:
 
 
 def plan_double(blk, fp8=False, fp8_attention: bool = False) -> DoublePlan:
-    """fp8: False | 'ln' (LayerNorm-fed projections) | 'all' (every projection of the block)."""
+    """fp8: False | 'ln' (LayerNorm-fed projections) | 'all' (every projection of the block, per-row scales, one quantise pass per
+    bf16 input) | 'mx' (every projection; the non-LayerNorm inputs as e4m3 + block scales written by their producers)."""
     a = blk.attn
     qi_w, qi_b = _fuse([a.to_q, a.to_k, a.to_v])
     qt_w, qt_b = _fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
@@ -143,7 +146,10 @@ def plan_double(blk, fp8=False, fp8_attention: bool = False) -> DoublePlan:
         pl.qkv_txt_w8, pl.qkv_txt_ws = ops.quantize_rows_fp8(pl.qkv_txt_w)
         pl.ff1_img_w8, pl.ff1_img_ws = ops.quantize_rows_fp8(pl.ff1_img_w)
         pl.ff1_txt_w8, pl.ff1_txt_ws = ops.quantize_rows_fp8(pl.ff1_txt_w)
-    if fp8 == "all":
+    if fp8 in ("all", "mx"):
+        pl.mx = fp8 == "mx"
+        if pl.mx and pl.out_img_w.shape[1] % 256:
+            raise ValueError("the 'mx' level needs an inner width that is a multiple of 256")
         pl.out_img_w8, pl.out_img_ws = ops.quantize_rows_fp8(pl.out_img_w)
         pl.out_txt_w8, pl.out_txt_ws = ops.quantize_rows_fp8(pl.out_txt_w)
         pl.ff2_img_w8, pl.ff2_img_ws = ops.quantize_rows_fp8(pl.ff2_img_w)
@@ -159,7 +165,10 @@ def plan_single(blk, fp8=False, fp8_attention: bool = False) -> SinglePlan:
                     a.norm_k.weight.data, blk.proj_out.weight.data, blk.proj_out.bias.data)
     if fp8:
         pl.fused_w8, pl.fused_ws = ops.quantize_rows_fp8(pl.fused_w)
-    if fp8 == "all":
+    if fp8 in ("all", "mx"):
+        pl.mx = fp8 == "mx"
+        if pl.mx and pl.out_w.shape[0] % 256:
+            raise ValueError("the 'mx' level needs an inner width that is a multiple of 256")
         pl.out_w8, pl.out_ws = ops.quantize_rows_fp8(pl.out_w)
     pl.fp8_attention = fp8_attention
     return pl
@@ -206,6 +215,13 @@ class Workspace:
         if getattr(self, "_a8", None) is None or self._a8.shape[2] < width:
             self._a8 = torch.empty(self.B, self.S, max(width, 5 * self.d), device=self._device, dtype=ops.FP8)
         return self._a8[:, :, :width]
+
+
+    def mx_scales(self) -> "ops.BlockScales":
+        """E8M0 block scales of the fp8_wide buffer (one plane per 256 columns, sized for 5d)."""
+        if getattr(self, "_a8s", None) is None:
+            self._a8s = ops.BlockScales.empty(self.B, self.S, 5 * self.d, self._device)
+        return self._a8s
 
 
 _WS_CACHE = {}
@@ -331,16 +347,26 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
         ops.linear_grouped([P(xn_i, pl.qkv_img_w, ws.qkv[:, T:], bias=pl.qkv_img_b), P(xn_t, pl.qkv_txt_w, ws.qkv[:, :T], bias=pl.qkv_txt_b)])
     q, k, v = ws.qkv[..., :d], ws.qkv[..., d : 2 * d], ws.qkv[..., 2 * d :]
     if pl.fp8_attention:
-        # 4.-6. RMSNorm(q,k) + RoPE -> e4m3 q|k and permuted Vᵀ, e4m3 joint attention; output over q
+        # 4.-6. RMSNorm(q,k) + RoPE -> e4m3 q|k and permuted Vᵀ, e4m3 joint attention; output over q ("mx": straight into the
+        # out-projections' e4m3 operand with its block scales)
         qk8, vt8 = ws.fp8_attn_buffers(H)
         ops.attention_fp8_prep(ws.qkv, 0, d, 2 * d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin, qk8, vt8)
-        ops.attention_fp8(qk8, vt8, q, H)
+        if pl.mx:
+            ops.attention_fp8_mx(qk8, vt8, ws.fp8_wide(d), ws.mx_scales(), H)
+        else:
+            ops.attention_fp8(qk8, vt8, q, H)
     else:
         # 4.-5. RMSNorm(q,k) + RoPE in place; 6. joint attention; output over q
         ops.qk_rmsnorm_rope(ws.qkv, 0, d, H, T, pl.nq_txt, pl.nk_txt, pl.nq_img, pl.nk_img, cos, sin)
         ops.attention(q, k, v, q, H)
     # 7./8. x += gate_msa * out_proj(attn)
-    if pl.out_img_w8 is not None:
+    if pl.mx:
+        a8, sc = ws.fp8_wide(d), ws.mx_scales()
+        if not pl.fp8_attention:
+            ops.quantize_mx_fp8_into(q, a8, sc)
+        ops.linear_grouped([P(a8[:, T:], pl.out_img_w8, x_i, bias=pl.out_img_b, gate=ch(mi, 2), res=x_i, a_bscale=sc.rows(T), w_scale=pl.out_img_ws),
+                            P(a8[:, :T], pl.out_txt_w8, x_t, bias=pl.out_txt_b, gate=ch(mt, 2), res=x_t, a_bscale=sc.rows(0), w_scale=pl.out_txt_ws)])
+    elif pl.out_img_w8 is not None:
         a8 = ws.fp8_wide(d)
         ops.quantize_rows_fp8_into(q[:, T:], a8[:, T:], ws.xs_i)
         ops.quantize_rows_fp8_into(q[:, :T], a8[:, :T], ws.xs_t)
@@ -352,14 +378,20 @@ def run_double(pl: DoublePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     if fp8:
         ops.layernorm_modulate_fp8(x_i, xn8_i, ws.xs_i, ch(mi, 3), ch(mi, 4))
         ops.layernorm_modulate_fp8(x_t, xn8_t, ws.xs_t, ch(mt, 3), ch(mt, 4))
-        ops.linear_grouped([P(xn8_i, pl.ff1_img_w8, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0, a_scale=ws.xs_i, w_scale=pl.ff1_img_ws),
-                            P(xn8_t, pl.ff1_txt_w8, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0, a_scale=ws.xs_t, w_scale=pl.ff1_txt_ws)])
+        # "mx": the GELU hidden leaves the epilogue as e4m3 + block scales (ffh is not written)
+        h8, hs = (ws.fp8_wide(4 * d), ws.mx_scales()) if pl.mx else (None, None)
+        o8 = lambda r0, r1: dict(out8=h8[:, r0:r1], out8_scales=hs.rows(r0), out8_from=0) if pl.mx else {}
+        ops.linear_grouped([P(xn8_i, pl.ff1_img_w8, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0, a_scale=ws.xs_i, w_scale=pl.ff1_img_ws, **o8(T, ws.S)),
+                            P(xn8_t, pl.ff1_txt_w8, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0, a_scale=ws.xs_t, w_scale=pl.ff1_txt_ws, **o8(0, T))])
     else:
         ops.layernorm_modulate(x_i, xn_i, ch(mi, 3), ch(mi, 4))
         ops.layernorm_modulate(x_t, xn_t, ch(mt, 3), ch(mt, 4))
         ops.linear_grouped([P(xn_i, pl.ff1_img_w, ws.ffh[:, T:], bias=pl.ff1_img_b, gelu_from=0),
                             P(xn_t, pl.ff1_txt_w, ws.ffh[:, :T], bias=pl.ff1_txt_b, gelu_from=0)])
-    if pl.ff2_img_w8 is not None:
+    if pl.mx:
+        ops.linear_grouped([P(h8[:, T:], pl.ff2_img_w8, x_i, bias=pl.ff2_img_b, gate=ch(mi, 5), res=x_i, add2=inject, a_bscale=hs.rows(T), w_scale=pl.ff2_img_ws),
+                            P(h8[:, :T], pl.ff2_txt_w8, x_t, bias=pl.ff2_txt_b, gate=ch(mt, 5), res=x_t, a_bscale=hs.rows(0), w_scale=pl.ff2_txt_ws)])
+    elif pl.ff2_img_w8 is not None:
         a8 = ws.fp8_wide(4 * d)
         ops.quantize_rows_fp8_into(ws.ffh[:, T:], a8[:, T:], ws.xs_i)
         ops.quantize_rows_fp8_into(ws.ffh[:, :T], a8[:, :T], ws.xs_t)
@@ -383,7 +415,9 @@ def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     if pl.fused_w8 is not None:
         xn8 = ws.fp8_buffers()
         ops.layernorm_modulate_fp8(ws.x, xn8, ws.xs_all, m[:, :d], m[:, d : 2 * d])
-        ops.linear(xn8, pl.fused_w8, big, bias=pl.fused_b, gelu_from=3 * d, a_scale=ws.xs_all, w_scale=pl.fused_ws)
+        # "mx": the gelu(mlp) columns leave the epilogue as columns d.. of proj_out's e4m3 operand [attn|mlp], with their block scales
+        o8 = dict(out8=ws.fp8_wide(5 * d)[..., d:], out8_scales=ws.mx_scales().cols(d), out8_from=3 * d) if pl.mx else {}
+        ops.linear(xn8, pl.fused_w8, big, bias=pl.fused_b, gelu_from=3 * d, a_scale=ws.xs_all, w_scale=pl.fused_ws, **o8)
     else:
         ops.layernorm_modulate(ws.x, ws.xn, m[:, :d], m[:, d : 2 * d])
         ops.linear(ws.xn, pl.fused_w, big, bias=pl.fused_b, gelu_from=3 * d)    # [k|v|q|gelu(mlp)]
@@ -391,11 +425,19 @@ def run_single(pl: SinglePlan, ws: Workspace, temb: torch.Tensor, cos, sin, H: i
     if pl.fp8_attention:
         qk8, vt8 = ws.fp8_attn_buffers(H)
         ops.attention_fp8_prep(big, 2 * d, 0, d, H, 0, None, None, pl.nq, pl.nk, cos, sin, qk8, vt8)
-        ops.attention_fp8(qk8, vt8, q, H)
+        if pl.mx:
+            ops.attention_fp8_mx(qk8, vt8, ws.fp8_wide(5 * d)[..., :d], ws.mx_scales(), H)
+        else:
+            ops.attention_fp8(qk8, vt8, q, H)
     else:
         ops.qk_rmsnorm_rope(big, 2 * d, 0, H, 0, None, None, pl.nq, pl.nk, cos, sin)
         ops.attention(q, big[..., :d], big[..., d : 2 * d], q, H)
-    if pl.out_w8 is not None:
+    if pl.mx:
+        a8, sc = ws.fp8_wide(5 * d), ws.mx_scales()
+        if not pl.fp8_attention:
+            ops.quantize_mx_fp8_into(q, a8[..., :d], sc)
+        ops.linear(a8, pl.out_w8, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x, a_bscale=sc, w_scale=pl.out_ws)
+    elif pl.out_w8 is not None:
         a8 = ws.fp8_wide(5 * d)
         ops.quantize_rows_fp8_into(big[..., 2 * d :], a8, ws.xs_all)
         ops.linear(a8, pl.out_w8, ws.x, bias=pl.out_b, gate=m[:, 2 * d : 3 * d], res=ws.x, a_scale=ws.xs_all, w_scale=pl.out_ws)

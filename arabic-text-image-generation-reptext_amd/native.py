@@ -46,7 +46,7 @@ class GemmGroup(C.Structure):
         ("a_bscale", C.c_void_p), ("a_bscale_plane", C.c_int64), ("a_bscale_rows", C.c_int64),
         ("c8", C.c_void_p), ("c_bscale", C.c_void_p),
         ("ldc8", C.c_int64), ("stride_c8", C.c_int64), ("c_bscale_plane", C.c_int64), ("c_bscale_rows", C.c_int64),
-        ("c8_from", C.c_int32), ("reserved0", C.c_int32),
+        ("c8_from", C.c_int32), ("c_bscale_k0", C.c_int32),
     ]
 
 
@@ -72,7 +72,7 @@ SIGNATURES = {
     "rt_attention_fp8_vt_bytes": [_i32, _i32, _i32],
     "rt_attention_fp8_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_attention_fp8_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
-    "rt_attention_fp8_fwd_mx": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "rt_attention_fp8_fwd_mx": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp],
     "rt_embedding_gather": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "rt_rmsnorm_rows": [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "rt_softmax_rows_bias": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],

@@ -56,39 +56,63 @@ def _batched(t: torch.Tensor, name: str):
 @dataclass
 class BlockScales:
     """E8M0 block scales of an e4m3 activation tensor [B, R, D] (one byte per 32 consecutive elements of a row) in rt_gemm_group's
-    plane layout: ``t`` uint8 [D/256, B*R, 8] contiguous; byte (b, r, k) at t[k // 256, b*R + r, (k % 256) // 32]. ``rows(r0)`` /
-    ``cols(k0)`` address a sub-view of the e4m3 tensor (rows r0.. of every batch entry, columns k0.. with k0 % 256 == 0)."""
+    layout: ``t`` uint8 [ceil(D/1024), B*Rp/64, 8, 16, 4, 4] = [plane of 1024 columns][64-row chunk][K-tile of 128 columns][row & 15]
+    [32-block of the K-tile][row >> 4 & 3], Rp = R rounded up to 64 (rows between batch entries). ``rows(r0)`` / ``cols(k0)``
+    address a sub-view of the e4m3 tensor (rows r0.. of every batch entry, r0 % 64 == 0; columns k0.., k0 % 128 == 0: a GEMM's A
+    operand must start at column 0, producers may write at any k0)."""
 
     t: torch.Tensor
-    R: int
+    R: int                  # rows between batch entries (multiple of 64)
     row0: int = 0
     k0: int = 0
 
     @staticmethod
     def empty(B: int, R: int, D: int, device) -> "BlockScales":
-        if D % 256:
-            raise ValueError("block-scaled rows need D % 256 == 0")
-        return BlockScales(torch.empty(D // 256, B * R, 8, device=device, dtype=torch.uint8), R)
+        if D % 128:
+            raise ValueError("block-scaled rows need D % 128 == 0")
+        Rp = (R + 63) // 64 * 64
+        return BlockScales(torch.empty((D + 1023) // 1024, B * Rp // 64, 8, 16, 4, 4, device=device, dtype=torch.uint8), Rp)
 
     @property
     def plane(self) -> int:
         return self.t.stride(0)
 
     def rows(self, r0: int) -> "BlockScales":
+        if r0 % 64:
+            raise ValueError("row offset of block scales must be a multiple of 64 (text length T % 64 == 0)")
         return BlockScales(self.t, self.R, self.row0 + r0, self.k0)
 
     def cols(self, k0: int) -> "BlockScales":
-        if k0 % 256:
-            raise ValueError("column offset of block scales must be a multiple of 256")
+        if k0 % 128:
+            raise ValueError("column offset of block scales must be a multiple of 128")
         return BlockScales(self.t, self.R, self.row0, self.k0 + k0)
 
     def ptr(self) -> int:
+        """Device address of the view's row origin (the column origin k0 travels separately)."""
         if not self.t.is_cuda or self.t.dtype != torch.uint8 or not self.t.is_contiguous():
             raise TypeError("block scales must be a contiguous uint8 tensor on the GPU")
-        return self.t.data_ptr() + (self.k0 // 256) * self.plane + self.row0 * 8
+        return self.t.data_ptr() + (self.row0 // 64) * 2048
 
-    def planes_left(self) -> int:
-        return self.t.shape[0] - self.k0 // 256
+    def columns_left(self) -> int:
+        return self.t.shape[0] * 1024 - self.k0
+
+    def _rm(self) -> torch.Tensor:
+        """[rows_total, planes*32] row-major view-copy of the whole tensor (row = chunk*64 + i*16 + l15; col = plane*32 + ktile*4 + j)."""
+        P = self.t.shape[0]
+        return self.t.permute(1, 5, 3, 0, 2, 4).reshape(-1, P * 32)
+
+    def rowmajor(self, B: int, R: int, D: int) -> torch.Tensor:
+        """uint8 [B, R, D/32] copy of the view's scale bytes in plain row-major order (tests and tools)."""
+        return self._rm().view(-1, self.R, self.t.shape[0] * 32)[:B, self.row0 : self.row0 + R, self.k0 // 32 : (self.k0 + D) // 32].contiguous()
+
+    def set_rowmajor(self, sb: torch.Tensor) -> None:
+        """Inverse of rowmajor(): write scale bytes given as uint8 [B, R, D/32] into the view (tests and tools)."""
+        B, R, nb = sb.shape
+        P = self.t.shape[0]
+        full = self._rm().view(-1, self.R, P * 32).clone()
+        full[:B, self.row0 : self.row0 + R, self.k0 // 32 : self.k0 // 32 + nb] = sb.to(full.device)
+        C = self.t.shape[1]
+        self.t.copy_(full.view(C, 4, 16, P, 8, 4).permute(3, 0, 4, 2, 5, 1))
 
 
 @dataclass
@@ -145,15 +169,16 @@ class LinearProblem:
                     raise ValueError("w_scale must be contiguous with N elements")
                 g.w_scale = _dev(self.w_scale, "w_scale", F32)
             if self.a_bscale is not None:
-                if K % 256 or self.a_bscale.planes_left() < K // 256:
-                    raise ValueError("block-scaled a: K % 256 == 0 and one scale plane per 256 columns")
+                if self.a_bscale.k0 != 0 or self.a_bscale.columns_left() < K:
+                    raise ValueError("block-scaled a: the operand starts at column 0 of its scale tensor, which must cover K")
                 g.a_bscale, g.a_bscale_plane, g.a_bscale_rows = self.a_bscale.ptr(), self.a_bscale.plane, self.a_bscale.R
             if self.out8 is not None:
                 B8, M8, N8, ld8, s8 = _batched(self.out8, "out8")
-                if self.out8_scales is None or (B8, M8) != (Bt, M) or N8 != N - self.out8_from or self.out8_scales.planes_left() < (N8 + 255) // 256:
+                if self.out8_scales is None or (B8, M8) != (Bt, M) or N8 != N - self.out8_from or self.out8_scales.columns_left() < N8:
                     raise ValueError("out8 must be [.., M, N - out8_from] e4m3 with its block scales")
                 g.c8, g.c_bscale = _dev(self.out8, "out8", FP8), self.out8_scales.ptr()
                 g.ldc8, g.stride_c8, g.c_bscale_plane, g.c_bscale_rows, g.c8_from = ld8, s8, self.out8_scales.plane, self.out8_scales.R, int(self.out8_from)
+                g.c_bscale_k0 = self.out8_scales.k0
         elif self.a_scale is not None or self.w_scale is not None or self.a_bscale is not None or self.out8 is not None:
             raise TypeError("a_scale / w_scale / block scales belong to fp8 problems")
         if self.out.dtype not in (BF16, F32):
@@ -335,22 +360,21 @@ def quantize_mx_fp8_into(x: torch.Tensor, out: torch.Tensor, scales: BlockScales
     B, R, D = x.shape
     if x.dtype not in (BF16, F32):
         raise TypeError("x must be bf16 or f32")
-    if D % 256 or scales.planes_left() < D // 256:
-        raise ValueError("D % 256 == 0 and one scale plane per 256 columns")
+    if D % 256 or scales.k0 != 0 or scales.columns_left() < D:
+        raise ValueError("D % 256 == 0, written from column 0 of a scale tensor that covers D")
     lib, st = native.load(), _stream()
     esz = x.element_size()
     _dev(out, "out", FP8), _dev(x, "x")
     for b in range(B):
         native.check("rt_quantize_mx_fp8", lib.rt_quantize_mx_fp8(
             x.data_ptr() + b * x.stride(0) * esz, x.stride(1), int(x.dtype == F32), out.data_ptr() + b * out.stride(0), out.stride(1),
-            scales.ptr() + b * scales.R * 8, scales.plane, R, D, st))
+            scales.ptr() + b * (scales.R // 64) * 2048, scales.plane, R, D, st))
 
 
 def dequantize_mx(q: torch.Tensor, scales: BlockScales) -> torch.Tensor:
     """fp32 [B,R,D] value of an e4m3 tensor with block scales (host-side helper for tests and tools; torch ops)."""
     B, R, D = q.shape
-    t = scales.t[scales.k0 // 256 : scales.k0 // 256 + D // 256].view(D // 256, -1, scales.R, 8)[:, :B, scales.row0 : scales.row0 + R]   # [D/256, B, R, 8]
-    e = t.permute(1, 2, 0, 3).reshape(B, R, D // 32).to(torch.float32) - 127.0
+    e = scales.rowmajor(B, R, D).to(torch.float32) - 127.0
     return (q.to(torch.float32).view(B, R, D // 32, 32) * torch.exp2(e).unsqueeze(-1)).view(B, R, D)
 
 
@@ -448,10 +472,10 @@ def attention_fp8_mx(qk8: torch.Tensor, vt8: torch.Tensor, out8: torch.Tensor, s
     B, S, _ = qk8.shape
     if out8.dim() != 3 or out8.shape[0] != B or out8.shape[1] != S or out8.stride(2) != 1:
         raise ValueError("out8 must be [B,S,*] with unit inner stride")
-    if scales.planes_left() < (H * 128) // 256:
-        raise ValueError("one scale plane per 256 output columns")
+    if scales.columns_left() < H * 128:
+        raise ValueError("the scale tensor must cover the H*128 output columns")
     native.check("rt_attention_fp8_fwd_mx", native.load().rt_attention_fp8_fwd_mx(
-        _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), _dev(out8, "out8", FP8), out8.stride(1), out8.stride(0), scales.ptr(), scales.plane, scales.R,
+        _dev(qk8, "qk8", FP8), _dev(vt8, "vt8", FP8), _dev(out8, "out8", FP8), out8.stride(1), out8.stride(0), scales.ptr(), scales.plane, scales.R, scales.k0,
         B, S, H, float(scale if scale is not None else 128 ** -0.5), _stream()))
     return out8
 

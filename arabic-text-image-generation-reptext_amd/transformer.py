@@ -108,9 +108,12 @@ class _MMDiTBase(nn.Module, WeightsIO):
         per output channel when the plans are (re)built, activations per token inside the LayerNorm kernel; everything else
         (attention, out/down projections, residual stream, adaLN) is unchanged. Accuracy: e4m3 carries 3 mantissa bits —
         see DESIGN.md §4 for the measured floor. ``on="all"`` adds to_out / to_add_out, ff.net.2 and proj_out, whose bf16 inputs
-        (attention output, GELU hidden) are quantised per token by one extra pass each."""
-        if on not in (True, False, "ln", "all"):
-            raise ValueError("enable_fp8_linears: True/'ln' (LayerNorm-fed projections), 'all' (every block projection), or False")
+        (attention output, GELU hidden) are quantised per token by one extra pass each. ``on="mx"``: the same projections, but
+        those inputs carry one E8M0 scale per 32 elements (MX block scaling, applied by the MFMA's scale operand) and are written
+        as e4m3 by the epilogue that computes them — the GELU hidden by the ff.net.0 / fused GEMM, the attention output by the
+        e4m3 attention kernel (a block-quantise pass only when the bf16 attention kernel is in use): no separate passes."""
+        if on not in (True, False, "ln", "all", "mx"):
+            raise ValueError("enable_fp8_linears: True/'ln' (LayerNorm-fed projections), 'all' / 'mx' (every block projection), or False")
         self._fp8_linears = "ln" if on is True else on
         self._plans = None
         return self

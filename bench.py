@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--inference-steps", type=int, default=28)
     ap.add_argument("--text-lines", type=int, default=1)
-    ap.add_argument("--precision", choices=["bf16", "fp8-ln", "fp8"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "fp8-ln", "fp8", "fp8-mx"], default="bf16",
                     help="bf16 = BASELINE config 2 (the headline); config 5's 'fp8 weights': fp8-ln = LayerNorm-fed projections on the e4m3 "
-                         "MFMA path, fp8 = every projection of the blocks")
+                         "MFMA path, fp8 = every projection of the blocks (per-row scales, quantise passes) + e4m3 attention, fp8-mx = the same with "
+                         "MX block-scaled operands written by the attention / GELU epilogues (no quantise passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of the loop from the host each pass instead of replaying the captured hipGraph")
@@ -100,7 +101,7 @@ class GemmTimer:
         self.ops = ops_mod
         self.events, self.flops, self.fp8, self.shapes = [], [], [], []
         self.att_events, self.att_flops = [], []
-        self._orig = self._orig_att = self._orig_att8 = None
+        self._orig = self._orig_att = self._orig_att8 = self._orig_att8mx = None
 
     def __enter__(self):
         ops = self.ops
@@ -124,7 +125,7 @@ class GemmTimer:
 
         ops.linear_grouped = timed
         # the second MFMA kernel of the path, timed the same way (reported beside the roofline of the dominant one)
-        self._orig_att, self._orig_att8 = ops.attention, ops.attention_fp8
+        self._orig_att, self._orig_att8, self._orig_att8mx = ops.attention, ops.attention_fp8, ops.attention_fp8_mx
 
         def timed_att(q, k, v, out, H, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -144,12 +145,21 @@ class GemmTimer:
             self.att_flops.append(4 * qk8.shape[0] * H * qk8.shape[1] * qk8.shape[1] * 128)
             return r
 
-        ops.attention, ops.attention_fp8 = timed_att, timed_att8
+        def timed_att8mx(qk8, vt8, out8, scales, H, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self._orig_att8mx(qk8, vt8, out8, scales, H, *a, **kw)
+            e1.record()
+            self.att_events.append((e0, e1))
+            self.att_flops.append(4 * qk8.shape[0] * H * qk8.shape[1] * qk8.shape[1] * 128)
+            return r
+
+        ops.attention, ops.attention_fp8, ops.attention_fp8_mx = timed_att, timed_att8, timed_att8mx
         return self
 
     def __exit__(self, *a):
         self.ops.linear_grouped = self._orig
-        self.ops.attention, self.ops.attention_fp8 = self._orig_att, self._orig_att8
+        self.ops.attention, self.ops.attention_fp8, self.ops.attention_fp8_mx = self._orig_att, self._orig_att8, self._orig_att8mx
 
     def attention_result(self):
         torch.cuda.synchronize()
@@ -340,10 +350,10 @@ def main():
     transformer = FluxTransformer2DModel(**tkw, device=dev, dtype=bf16).random_init_(seed=0)
     controlnet = FluxControlNetModel(**cfg_c, device=dev, dtype=bf16).random_init_(seed=1)   # zero-linears random too
     if args.precision != "bf16":
-        level = "ln" if args.precision == "fp8-ln" else "all"
+        level = {"fp8-ln": "ln", "fp8": "all", "fp8-mx": "mx"}[args.precision]
         transformer.enable_fp8_linears(level)
         controlnet.enable_fp8_linears(level)
-        if args.precision == "fp8":
+        if args.precision in ("fp8", "fp8-mx"):
             transformer.enable_fp8_attention(True)
             controlnet.enable_fp8_attention(True)
     vae = AutoencoderKL(**flux_vae_config(), device=dev, dtype=bf16).random_init_(seed=2)
@@ -457,7 +467,8 @@ def main():
     n_tower = tower_blocks_read(cfg_t, cfg_c)
     fl_img = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c, tower_blocks=n_tower)   # EXECUTED work
     fl_img_ref = flops_per_image(H, W, args.inference_steps, args.text_lines, cfg_t, cfg_c)                    # the reference's count
-    e2e_peak = 5.0e15 if args.precision == "fp8" else 2.5e15                    # dense MFMA peak of the dtype the projections run in
+    full8 = args.precision in ("fp8", "fp8-mx")
+    e2e_peak = 5.0e15 if full8 else 2.5e15                    # dense MFMA peak of the dtype the projections run in
 
     roofline = None
     if rank == 0 and not args.no_roofline_pass:
@@ -483,8 +494,8 @@ def main():
         roofline["per_shape"] = gt.per_shape(fp8=None if args.precision == "bf16" else True, peak_tflops=peak)
         na, fla, seca = gt.attention_result()
         if na:
-            pk = 2500.0 if args.precision != "fp8" else 5000.0
-            roofline["attention_kernel"] = {"kernel": ("attention_v3_kernel (attention_fwd_kernel for S < 1536 or S % 256 != 0)" if args.precision != "fp8"
+            pk = 5000.0 if full8 else 2500.0
+            roofline["attention_kernel"] = {"kernel": ("attention_v3_kernel (attention_fwd_kernel for S < 1536 or S % 256 != 0)" if not full8
                                                        else "attention_fp8_kernel"), "launches": na,
                                             "avg_launch_us": round(seca / na * 1e6, 2), "achieved": round(fla / seca / 1e12, 1), "peak": pk,
                                             "frac": round(fla / seca / (pk * 1e12), 4)}
@@ -506,7 +517,9 @@ def main():
             "vae_decode_ms_per_step": None if dec_ms is None else round(dec_ms, 2),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8-ln": "fp8 (e4m3 to_q/k/v, add_*_proj, ff.net.0, proj_mlp) + bf16",
-                      "fp8": "fp8 (e4m3 block projections and attention; bf16 storage, fp32 residual stream)"}[args.precision], "data": "synthetic",
+                      "fp8": "fp8 (e4m3 block projections and attention; bf16 storage, fp32 residual stream)",
+                      "fp8-mx": "fp8 (e4m3 block projections and attention, MX block-scaled activations out of the attention / GELU epilogues; "
+                                "fp32 residual stream)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"FLUX.1-dev (19+38 blocks) + RepText ControlNet (6+0), {H}x{W}, {args.inference_steps} steps, "
                                    f"{args.text_lines} text line(s), batch {Bl}/GPU on rank 0, denoise loop + VAE decode to uint8, random-init weights; "
                                    f"tower blocks evaluated {n_tower} of {cfg_c['num_layers']} (the last sample is never read, Q5)",

@@ -79,21 +79,26 @@ typedef struct rt_gemm_group {
   int64_t stride_rowscale; /* elements between the rowscale vectors of consecutive batch entries; 0 = one vector shared by the
                             * batch (the reference's one mask per text line); > 0: a mask per image of a sharded batch        */
   /* MX block scales (ABI 8; rt_gemm_fp8 only, ignored by rt_gemm_bf16). An activation row carries one E8M0 byte s (value
-   * 2^(s-127)) per 32 consecutive K-elements, kept in planes of 256 K-elements so that the 256 rows x 8 bytes a GEMM tile needs
-   * per two K-tiles are one contiguous 2-KiB piece:   byte(b, m, k) = base + (k/256)*plane + (b*rows + m)*8 + (k%256)/32.
-   *  a_bscale != NULL: A's block scales, applied by the MFMA itself (v_mfma_scale_f32_16x16x128_f8f6f4's scale operand) before
-   *    the fp32 accumulation; K % 256 == 0; a_scale may be NULL (usual) or given as well.
+   * 2^(s-127)) per 32 consecutive K-elements. Scale tensors are laid out for the consuming GEMM wave: planes of 1024 K-elements
+   * (8 K-tiles; a last partial plane is allocated whole); inside a plane 64-row chunks of 2 KiB in the order
+   * [K-tile][row & 15][32-block of the K-tile][row >> 4 & 3]:
+   *   byte(r, k) = base + (k/1024)*plane + (r/64)*2048 + ((k%1024)/128)*256 + (r%16)*16 + ((k%128)/32)*4 + (r/16)%4,  r = b*rows + m
+   * (rt_common.h: rt_mx_scale_offset). base 16-byte aligned, plane % 2048 == 0, rows % 64 == 0 (rows = row count between batch
+   * entries; a view that starts at row r0 of every entry passes base + (r0/64)*2048, r0 % 64 == 0).
+   *  a_bscale != NULL: A's block scales (column 0 of A = k 0 of the scale tensor), applied by the MFMA itself
+   *    (v_mfma_scale_f32_16x16x128_f8f6f4's scale operand) before the fp32 accumulation; a_scale may be NULL (usual) or given as well.
    *  c8 != NULL: columns n >= c8_from are NOT written to C; the epilogue value v (after every term) is quantised per 32 columns —
    *    s = the smallest exponent byte with max|v| <= 448 * 2^(s-127) (rt_quantize_mx_fp8's rule) — and stored as
-   *    e4m3(v * 2^(127-s)) at c8[b*stride_c8 + m*ldc8 + (n - c8_from)] with s at the byte the layout above gives for
-   *    k = n - c8_from under (c_bscale, c_bscale_plane, c_bscale_rows): the next GEMM's A and a_bscale, with no pass in between.
+   *    e4m3(v * 2^(127-s)) at c8[b*stride_c8 + m*ldc8 + (n - c8_from)] with s at byte(b*c_bscale_rows + m, c_bscale_k0 + n - c8_from)
+   *    of (c_bscale, c_bscale_plane): the next GEMM's A and a_bscale, with no pass in between (c_bscale_k0 = the column of that A
+   *    at which c8 starts, % 32 == 0).
    *    c8_from % 256 == 0, (N - c8_from) % 32 == 0, ldc8 % 8 == 0, c8 8-byte aligned. */
   const uint8_t* a_bscale;
   int64_t a_bscale_plane, a_bscale_rows;
   uint8_t* c8;
   uint8_t* c_bscale;
   int64_t ldc8, stride_c8, c_bscale_plane, c_bscale_rows;
-  int32_t c8_from, reserved0;
+  int32_t c8_from, c_bscale_k0;
 } rt_gemm_group;
 
 int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
@@ -119,8 +124,8 @@ int rt_quantize_rows_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, i
 
 /* MX block quantisation of activation rows (config 5, "mx" level): per 32 consecutive elements one E8M0 scale byte
  * s = the smallest with max|x| <= 448 * 2^(s-127), clamped to [1, 253]; out = e4m3(x * 2^(127-s)), round to nearest even.
- * x bf16 (x_f32 = 0) or f32 [rows][ldx]; out bytes [rows][ldo]; scales in rt_gemm_group's plane layout
- * (bscale + (k/256)*plane + row*8 + (k%256)/32). D % 256 == 0. The fused producers (rt_gemm_fp8's c8 output,
+ * x bf16 (x_f32 = 0) or f32 [rows][ldx]; out bytes [rows][ldo]; scales in rt_gemm_group's layout (byte(row, k) there; bscale
+ * 16-byte aligned, plane % 2048 == 0 and >= ceil(rows/64)*2048). D % 256 == 0. The fused producers (rt_gemm_fp8's c8 output,
  * rt_attention_fp8_fwd_mx) apply the same rule to their fp32 results; this pass serves tensors no fused producer writes. */
 int rt_quantize_mx_fp8(const void* x, int64_t ldx, int32_t x_f32, void* out, int64_t ldo, uint8_t* bscale, int64_t plane,
                        int32_t rows, int32_t D, void* stream);
@@ -206,12 +211,13 @@ int rt_attention_fp8_prep(const void* buf, int64_t ld, int64_t stride_b, int64_t
 int rt_attention_fp8_fwd(const void* qk8, const void* vt8, void* o, int64_t ldo, int64_t stride_ob,
                          int32_t B, int32_t S, int32_t H, float scale, void* stream);
 /* The same attention with the output written as the NEXT projection's e4m3 A operand (config 5, "mx" level): o8[b][q][h*128 + d]
- * = e4m3(o * 2^(127-s)) with one E8M0 byte s per (row, 32 columns) in rt_gemm_group's plane layout (rt_quantize_mx_fp8's rule
- * applied to the fp32 output; no bf16 store and no quantisation pass in between): bscale + ((h*128 + d)/256)*plane +
- * (b*bscale_rows + q)*8 + ((h*128 + d)%256)/32. H even. Replaces `F.scaled_dot_product_attention` + the operand cast of to_out /
+ * = e4m3(o * 2^(127-s)) with one E8M0 byte s per (row, 32 columns) in rt_gemm_group's scale layout (rt_quantize_mx_fp8's rule
+ * applied to the fp32 output; no bf16 store and no quantisation pass in between): byte(b*bscale_rows + q, bscale_k0 + h*128 + d).
+ * bscale_rows % 64 == 0, bscale_k0 % 128 == 0. Replaces `F.scaled_dot_product_attention` + the operand cast of to_out /
  * proj_out (A.1 steps 6-7, A.2) on the e4m3 path. */
 int rt_attention_fp8_fwd_mx(const void* qk8, const void* vt8, void* o8, int64_t ldo8, int64_t stride_ob8, uint8_t* bscale,
-                            int64_t plane, int64_t bscale_rows, int32_t B, int32_t S, int32_t H, float scale, void* stream);
+                            int64_t plane, int64_t bscale_rows, int32_t bscale_k0, int32_t B, int32_t S, int32_t H, float scale,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Prompt encoders (PIPE:232-347: T5-XXL encoder -> prompt_embeds [B,512,4096], CLIP-L text model ->

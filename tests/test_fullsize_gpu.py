@@ -52,6 +52,15 @@ def test_real_width_blocks_vs_oracle(gpu):
     e, e8, floor = rel_l2(out8, ref), rel_l2(out8, ref8), rel_l2(ref8, ref)
     print(f"real-width e4m3 projections + attention rel-L2 {e:.3e} vs fp32 oracle, {e8:.3e} vs e4m3 oracle (floor {floor:.3e})")
     assert e <= 1.25 * floor + 1e-4 and e8 <= 1.45 * floor + 1e-4
+    # the same with block-scaled ("mx") operands written by the attention / GELU epilogues
+    tr.enable_fp8_linears("mx")
+    outm = tr(hidden_states=b16(lat), encoder_hidden_states=b16(pe), pooled_projections=b16(pooled), timestep=ts.to(gpu), img_ids=b16(ids),
+              txt_ids=b16(tids), guidance=gd.to(gpu), return_dict=False)[0].float().cpu()
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("mx"), orc.fp8_attention():
+        refm = orc.transformer_forward(tp, WIDE, lat, pe, pooled, ts, ids, tids, guidance=gd)
+    em, em8, floorm = rel_l2(outm, ref), rel_l2(outm, refm), rel_l2(refm, ref)
+    print(f"real-width mx projections + attention rel-L2 {em:.3e} vs fp32 oracle, {em8:.3e} vs mx oracle (floor {floorm:.3e})")
+    assert em <= 1.25 * floorm + 1e-4 and em8 <= 1.45 * floorm + 1e-4
 
 
 def test_linear_properties_at_c2_shapes(gpu):

@@ -189,6 +189,18 @@ def test_fp8_linears_transformer_and_tower(gpu):
     print(f"fp8-all transformer rel-L2 {erra:.3e} vs fp32 oracle, {err8a:.3e} vs fp8 oracle (floor {floora:.3e})")
     assert_at_dtype_floor(erra, err8a, floora)
     assert erra < 3e-2
+    # level "mx": the same projections with E8M0 block scales; GELU hidden quantised in the producing epilogue, the bf16 attention
+    # output by one block-quantise pass
+    tr.enable_fp8_linears("mx")
+    out8m = call_t()
+    assert not torch.equal(out8m, out8a)
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("mx"):
+        ref8m = orc.transformer_forward(*targs, guidance=x["guidance"])
+    errm, err8m, floorm = rel_l2(out8m, ref), rel_l2(out8m, ref8m), rel_l2(ref8m, ref)
+    print(f"fp8-mx transformer rel-L2 {errm:.3e} vs fp32 oracle, {err8m:.3e} vs mx oracle (floor {floorm:.3e}; per-row 'all' floor {floora:.3e})")
+    assert_at_dtype_floor(errm, err8m, floorm)
+    assert errm < 3e-2
+    assert torch.equal(call_t(), out8m)                                   # bitwise repeatable
     tr.enable_fp8_linears(False)
     assert torch.equal(call_t(), out16)                                   # and switching back restores the bf16 path bit for bit
     # tower
@@ -223,3 +235,13 @@ def test_fp8_attention_in_model(gpu):
     print(f"fp8 linears+attention transformer rel-L2 {err:.3e} vs fp32 oracle, {err8:.3e} vs fp8 oracle (floor {floor:.3e})")
     assert_at_dtype_floor(err, err8, floor)
     assert err < 3e-2
+    # the fused form of config 5: block-scaled operands written by the attention and GELU epilogues, no quantisation passes
+    tr.enable_fp8_linears("mx")
+    outm = tr(hidden_states=d["latents"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["timestep"],
+              img_ids=d["img_ids"], txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0].float().cpu()
+    with orc.stored_as(torch.bfloat16), orc.fp8_linears("mx"), orc.fp8_attention():
+        refm = orc.transformer_forward(*targs, guidance=x["guidance"])
+    errm, err8m, floorm = rel_l2(outm, ref), rel_l2(outm, refm), rel_l2(refm, ref)
+    print(f"mx linears+attention transformer rel-L2 {errm:.3e} vs fp32 oracle, {err8m:.3e} vs mx oracle (floor {floorm:.3e})")
+    assert_at_dtype_floor(errm, err8m, floorm)
+    assert errm < 3e-2

@@ -27,9 +27,8 @@ def ops(gpu):
 
 
 def _scales_of(ops, sc, B, R, D):
-    """[B, R, D/32] uint8 view of a BlockScales (host copy)."""
-    t = sc.t[sc.k0 // 256 : sc.k0 // 256 + D // 256].cpu().view(D // 256, -1, sc.R, 8)[:, :B, sc.row0 : sc.row0 + R]
-    return t.permute(1, 2, 0, 3).reshape(B, R, D // 32)
+    """[B, R, D/32] uint8 scale bytes of a BlockScales view in plain row-major order (host copy)."""
+    return sc.rowmajor(B, R, D).cpu()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -68,8 +67,8 @@ def test_gemm_with_block_scaled_operand(ops, gpu, M, N, K, batch):
     sw = torch.rand(N, generator=g) * 0.02 + 0.01
     bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
     sc = ops.BlockScales.empty(batch, M, K, gpu)
-    sb = torch.randint(107, 148, (K // 256, batch * M, 8), generator=g, dtype=torch.uint8)
-    sc.t.copy_(sb)
+    sc.t.fill_(127)
+    sc.set_rowmajor(torch.randint(107, 148, (batch, M, K // 32), generator=g, dtype=torch.uint8))
     a_deq = ops.dequantize_mx(a8.to(gpu), sc).cpu()
     ref = torch.einsum("bmk,nk->bmn", a_deq.double(), w8.float().double()) * sw.view(1, 1, N).double() + bias.double()
     out = torch.empty(batch, M, N, device=gpu, dtype=torch.float32)
@@ -86,11 +85,11 @@ def test_gemm_block_scaled_views_of_both_streams(ops, gpu):
     """The double blocks' shape: one e4m3 buffer [B, S, K] with text rows first, its two row ranges as the A operands of one grouped
     launch, scales addressed through BlockScales.rows()."""
     g = torch.Generator().manual_seed(11)
-    B, T, Ni, K, N = 2, 256, 512, 768, 512
+    B, T, Ni, K, N = 2, 192, 500, 768, 512
     S = T + Ni
     a8 = torch.randn(B, S, K, generator=g).to(FP8).to(gpu)
     sc = ops.BlockScales.empty(B, S, K, gpu)
-    sc.t.copy_(torch.randint(117, 138, tuple(sc.t.shape), generator=g, dtype=torch.uint8))
+    sc.set_rowmajor(torch.randint(117, 138, (B, S, K // 32), generator=g, dtype=torch.uint8))
     wi, wt = [(torch.randn(N, K, generator=g) * 0.5).to(FP8).to(gpu) for _ in range(2)]
     oi = torch.empty(B, Ni, N, device=gpu, dtype=torch.float32)
     ot = torch.empty(B, T, N, device=gpu, dtype=torch.float32)
@@ -129,7 +128,7 @@ def test_gemm_epilogue_writes_block_scaled_e4m3(ops, gpu, M, N, K, c8_from):
     assert torch.equal(big8[..., 256:].cpu().view(torch.uint8), q_ref.view(torch.uint8))
     assert torch.equal(out16[..., :c8_from], ref16[..., :c8_from])
     assert bool((out16[..., c8_from:] == 7.0).all())                   # those columns are not written to C
-    assert bool((big8[..., :256].view(torch.uint8) == 0).all()) and bool((sc.t[0] == 0).all())
+    assert bool((big8[..., :256].view(torch.uint8) == 0).all()) and bool((sc.rowmajor(batch, M, 256) == 0).all())
 
 
 @pytest.mark.parametrize("B,S,H,T", [(1, 256, 2, 64), (2, 200, 4, 40), (1, 1100, 2, 0)])

@@ -14,7 +14,8 @@ w8 = (torch.rand(N, K, generator=g) + 0.5).to(FP8)
 
 def run(sb):
     sc = ops.BlockScales.empty(1, M, K, gpu)
-    sc.t.copy_(sb)
+    sc.t.fill_(127)
+    sc.set_rowmajor(sb.permute(1, 0, 2).reshape(1, M, K // 32))
     out = torch.empty(1, M, N, device=gpu, dtype=torch.float32)
     ops.linear(a8.to(gpu), w8.to(gpu), out, a_bscale=sc)
     ref = torch.einsum("bmk,nk->bmn", ops.dequantize_mx(a8.to(gpu), sc).cpu().double(), w8.float().double())
@@ -37,7 +38,7 @@ for blk in range(16):
     best = None
     for cand in range(16):
         sbc = base.clone(); sbc[cand // 8, :, cand % 8] = 131
-        sc = ops.BlockScales.empty(1, M, K, gpu); sc.t.copy_(sbc)
+        sc = ops.BlockScales.empty(1, M, K, gpu); sc.set_rowmajor(sbc.permute(1, 0, 2).reshape(1, M, K // 32))
         rc = torch.einsum("bmk,nk->bmn", ops.dequantize_mx(a8.to(gpu), sc).cpu().double(), w8.float().double())
         e = float((o - rc).norm() / rc.norm())
         if best is None or e < best[1]:
