@@ -196,3 +196,29 @@ def test_streamed_params_feed_the_oracle_identically():
     got = config1_oracle(sp_t, cfg_t, sp_c, cfg_c, case)
     assert torch.equal(got, ref) and sp_t.bytes_streamed > 0 and len(sp_t) == len(tp) and "x_embedder.weight" in sp_t
     assert sp_t.get("no.such.bias") is None
+
+
+def test_mx_block_quantisation_known_answers():
+    """The E8M0 rule of the "mx" level (csrc/rt_common.h: rt_mx_scale_byte; oracle.flux_oracle.mx_scale_byte / quant_mx_e4m3): the
+    smallest power of two 2^(s-127) with amax <= 448 * 2^(s-127), from closed-form cases; the quantised block never exceeds 448,
+    de-quantises to within 2^-4 of every element (or half a subnormal step of the block), and re-quantising its own output is exact."""
+    import torch
+    from oracle import flux_oracle as orc
+
+    amax = torch.tensor([0.0, 1e-45, 448.0, 448.0001, 449.0, 511.9, 512.0, 896.0, 896.1, 1.75, 1.7500001, 1.0, 3.5, 2.0 ** -9 * 1.75, 1e38])
+    want = torch.tensor([1, 1, 127, 128, 128, 128, 128, 128, 129, 119, 120, 119, 120, 110, 245], dtype=torch.int32)
+    assert torch.equal(orc.mx_scale_byte(amax), want)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(6, 512, generator=g) * torch.logspace(-6, 5, 6)[:, None]
+    x[2, 32:64] = 0
+    q, sb = orc.quant_mx_e4m3(x, return_parts=True)
+    assert float(q.float().abs().max()) <= 448.0 and sb.shape == (6, 16)
+    assert int(sb[2, 1]) == 1 and bool((q.float()[2, 32:64] == 0).all())
+    d = orc.quant_mx_e4m3(x)
+    step = torch.exp2(sb.float() - 127.0 - 10.0).repeat_interleave(32, dim=-1)
+    assert bool(((d - x).abs() <= x.abs() * 2.0 ** -4 + step).all())
+    assert torch.equal(orc.quant_mx_e4m3(d), d)                     # idempotent
+    # every block uses the top binade of e4m3 it can: its largest element lands in [224, 448]
+    top = q.float().abs().reshape(6, 16, 32).amax(dim=-1)
+    nz = x.abs().reshape(6, 16, 32).amax(dim=-1) > 0
+    assert bool(((top >= 224.0) & (top <= 448.0))[nz].all())
