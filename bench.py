@@ -203,6 +203,8 @@ def pmc_traffic_bytes(kernel_key: str):
             d = json.load(f)
         if kernel_key.startswith("fp8:"):          # the passes over `bench.py --precision fp8`
             return int(d["fp8_run"]["kernels"][kernel_key[4:]]["hbm_bytes_per_launch_corrected"])
+        if kernel_key.startswith("fp8mx:"):        # ... --precision fp8-mx
+            return int(d["fp8mx_run"]["kernels"][kernel_key[6:]]["hbm_bytes_per_launch_corrected"])
         return int(d["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"])
     except Exception:
         return None
@@ -483,7 +485,7 @@ def main():
             peak, kname, tkey = 2500.0, "gemm_pp_kernel<bf16> (rt_gemm_bf16)", "gemm"
         else:                                    # dominant kernel of the fp8 run: the e4m3 instantiation, priced at the dense fp8 peak
             n_launch, fl, sec = gt.result(fp8=True)
-            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", "fp8:gemm_pp_kernel"
+            peak, kname, tkey = 5000.0, "gemm_pp_kernel<e4m3> (rt_gemm_fp8)", ("fp8mx:" if args.precision == "fp8-mx" else "fp8:") + "gemm_pp_kernel"
         ach = fl / sec / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic_bytes(tkey) if tkey else None, "kernel": kname, "launches": n_launch,

@@ -5,10 +5,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", f"prof_{tag}"), os.path.join(root, "profiles")
 for f in ("bench_c2_bf16.json", "bench_c2_fp8.json", "bench_c3_batch4_bf16.json", "bench_c5shape_1536_bf16.json", "bench_c5_1536_fp8.json",
-          "bench_under_rocprof_bf16.json", "bench_under_rocprof_fp8.json", "kernel_microbench.txt"):
+          "bench_under_rocprof_bf16.json", "bench_under_rocprof_fp8.json", "kernel_microbench.txt", "bench_c2_fp8mx.json", "bench_c5_1536_fp8mx.json",
+          "bench_under_rocprof_fp8mx.json", "bench_c4_inpaint.json", "mx_gemm_microbench.txt"):
     if os.path.isfile(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
-for f, g in (("stats_bf16_kernel_stats.csv", "bench_kernel_stats_bf16.csv"), ("stats_fp8_kernel_stats.csv", "bench_kernel_stats_fp8.csv"),
+for f, g in (("stats_bf16_kernel_stats.csv", "bench_kernel_stats_bf16.csv"), ("stats_fp8_kernel_stats.csv", "bench_kernel_stats_fp8.csv"), ("stats_fp8mx_kernel_stats.csv", "bench_kernel_stats_fp8mx.csv"),
              ("stats_vae_kernel_stats.csv", "vae_decode_kernel_stats.csv")):
     if os.path.isfile(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{g}"))
@@ -36,6 +37,8 @@ t = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                f"hbm_bytes = (2*FETCH + WRITE) KiB * 1024 (final kernels of round {tag})",
      "kernels": traffic(load("fetch_bf16.json"), load("write_bf16.json"), names_bf16),
      "fp8_run": {"source": "same with --precision fp8 (gemm_pp_kernel: e4m3 and the 7 % bf16 launches together, the counter records drop template arguments)", "kernels": traffic(load("fetch_fp8.json"), load("write_fp8.json"), names_fp8)},
+     "fp8mx_run": {"source": "same with --precision fp8-mx (no quantize_rows launches; block-scaled operands)",
+                   "kernels": traffic(load("fetch_fp8mx.json"), load("write_fp8mx.json"), {k: v for k, v in names_fp8.items() if k != "quantize_rows"})},
      "alone": {"source": "tools/prof_one.py (5 launches of one kernel, S = 4608 x 24 heads / 4608x21504x3072): attention_v3 (default) and attention.hip (RT_ATTN_V3=0) side by side",
                "kernels": {**traffic(load("pmc_attn_p4.json"), load("pmc_attn_p5.json"), {"attention_v3_kernel": "attention_v3_kernel"}),
                            **traffic(load("pmc_attnold_p4.json"), load("pmc_attnold_p5.json"), {"attention_fwd_kernel": "attention_fwd_kernel"}),
