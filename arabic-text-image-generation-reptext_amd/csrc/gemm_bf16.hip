@@ -72,7 +72,20 @@ struct Launch {
 // Epilogue for one wave: NI x NJ accumulator fragments -> C. Lane owns rows mrow + 16i and, per fragment column j,
 // the 4 consecutive columns ncol + 16j .. +3. Column-only terms (bias, gate) are loaded ONCE for the fragment columns;
 // per-row terms (residual, add2) are fetched one row ahead of the row being finished, so no store waits on a load.
-template <bool OUT_F32, bool FP8, int NI, int NJ>
+// CONV (rt_gemm_group::conv_ks > 0): rows are the pixels of a zero-haloed NHWC image in memory order; only interior pixels are stored
+// (the halo must stay zero) — rt_conv_interior decides per row.
+__device__ __forceinline__ bool rt_conv_interior(const rt_gemm_group& g, int p) {
+  // p < 2^24 (host check): the float quotient is within one of the exact one
+  int q = (int)((float)p * g.conv_inv_w2);
+  int x = p - q * g.conv_w2;
+  if (x < 0) { x += g.conv_w2; --q; } else if (x >= g.conv_w2) { x -= g.conv_w2; ++q; }
+  int b = (int)((float)q * g.conv_inv_h2);
+  int y = q - b * g.conv_h2;
+  if (y < 0) y += g.conv_h2; else if (y >= g.conv_h2) y -= g.conv_h2;
+  return x >= 1 && x <= g.conv_w2 - 2 && y >= 1 && y <= g.conv_h2 - 2;
+}
+
+template <bool OUT_F32, bool FP8, int NI, int NJ, bool CONV = false>
 __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, int mrow, int ncol, f32x4 (&acc)[NI][NJ], bool wide = false) {
   const int rpb = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   bool nok[NJ];
@@ -125,7 +138,8 @@ __device__ __forceinline__ void epilogue_tile(const rt_gemm_group& g, int bidx, 
   uint32_t sbw[(NJ + 1) / 2] = {};                     // MX output: scale bytes of four consecutive fragment rows per 32-column block
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int m = mrow + 16 * i;
+    // CONV: a halo pixel's row is computed like any other and dropped here (m = M disables every store of the row)
+    const int m = (CONV && !rt_conv_interior(g, mrow + 16 * i)) ? g.M : mrow + 16 * i;
     res_t rcur[NJ];
     u32x2 acur[NJ];
 #pragma unroll
@@ -296,10 +310,20 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 //              K order lane group g holds k = 16g..16g+15 in its first four registers and 64+16g.. in the other four — the chunks
 //              j and j+4 read above, so the hardware's K order IS the memory order — and the byte supplied by lane group b scales
 //              K-block b (k = 32b..32b+31) of that lane's row, whichever lanes hold those values: lane (row, j) supplies block j.
-template <bool FP8, class G_, bool MX = false>
+//
+// CONV = true (bf16 only): a stride-1 k x k convolution over a zero-haloed NHWC image as THIS GEMM (rt_gemm_group::conv_*): A = the
+//              image as a [pixels incl. halo][Cin] matrix in memory order, W = [Cout][k*k][Cin], K = k*k*Cin. For output pixel p
+//              (also a haloed position) tap (dy,dx) reads pixel p + (dy-1)(W+2) + (dx-1): the SAME row shift for every p, so K-tile kt
+//              (64 channels c0.. of one tap) is the ordinary A tile with its rows shifted by a wave-uniform number of pixels — added
+//              to the lanes' byte offsets (4 VALU adds per K-tile; the buffer descriptor's range check turns reads in front of or
+//              behind the image, which only halo rows make, into zeros) — and c0 in the scalar offset. Halo rows are computed and
+//              dropped in the epilogue (0.4-3 % of the rows). Everything else — tile, LDS image, ping-pong schedule, counted waits —
+//              is the GEMM's; the K order of an output element is that of csrc/vae.hip's conv_nhwc_kernel (bit-identical results).
+template <bool FP8, class G_, bool MX = false, bool CONV = false>
 __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int m0, int n0, bool wide_store, char* smem) {
   using T = G_;
   static_assert(!MX || FP8, "block scales belong to the e4m3 form");
+  static_assert(!CONV || !FP8, "the convolution form is bf16");
   constexpr int ESZ = FP8 ? 1 : 2;                   // bytes per operand element
   constexpr int BKE = 128 / ESZ;                     // elements per K-tile
   constexpr int NPC = T::PA0 + T::PB0 + T::PB1 + T::PA1;          // pieces per wave and K-tile
@@ -356,17 +380,38 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   }
   // LDS-DMA by buffer_load ... lds: 4-SGPR descriptor per operand + the lane's invariant 32-bit byte offset + the K offset in an
   // SGPR — no per-K-tile vector address arithmetic and half the address registers of the global_load form.
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab), 0, -1, 0x00020000);
+  // CONV: num_records = the image's bytes, so a shifted row in front of / behind the image reads zeros instead of foreign memory
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab), 0, CONV ? (int)((int64_t)g.M * g.lda * ESZ) : -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, -1, 0x00020000);
   // part 0 = a0, 1 = b0, 2 = b1, 3 = a1 (issue order inside a K-tile)
+  // CONV: K-tile kt = channels c0.. of tap; the A parts take (row shift of the tap in bytes -> lane offsets, c0 -> scalar offset)
+  int cv_shift = 0, cv_c0 = 0, cv_kx = 0;                               // of the K-tile being ISSUED
+  auto conv_at = [&](int kt) {                                           // position the issue state on K-tile kt (kt = 0 or the next one)
+    if constexpr (CONV) {
+      if (kt == 0) {
+        cv_c0 = 0;
+        cv_shift = g.conv_ks == 3 ? -(g.conv_w2 + 1) * (int)g.lda * 2 : 0;
+      } else {
+        cv_c0 += 128;                                                    // bytes
+        if (cv_c0 == g.conv_cin * 2) {                                   // next tap: +1 pixel, or from the row's third tap to the next row's first
+          cv_c0 = 0;
+          const bool wrap = ++cv_kx == 3;
+          if (wrap) cv_kx = 0;
+          cv_shift += (wrap ? g.conv_w2 - 2 : 1) * (int)g.lda * 2;
+        }
+      }
+    }
+  };
   auto issue = [&](auto part_c, int buf, int koff) {                     // koff in BYTES along the row
     constexpr int part = decltype(part_c)::value;
     constexpr int first = part == 0 ? 0 : part == 1 ? T::PA0 : part == 2 ? T::PA0 + T::PB0 : T::PA0 + T::PB0 + T::PB1;
     constexpr int cnt = part == 0 ? T::PA0 : part == 1 ? T::PB0 : part == 2 ? T::PB1 : T::PA1;
+    constexpr bool isA = part == 0 || part == 3;
 #pragma unroll
     for (int q = 0; q < cnt; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((part == 0 || part == 3) ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
-                                               (int)src[first + q], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
+                                               (CONV && isA) ? (int)src[first + q] + cv_shift : (int)src[first + q], (CONV && isA) ? cv_c0 : koff, 0, 0);
   };
   // MX: the scale piece of K-tile octet `oct` -> ring slot oct & 1. Wave w copies 1 KiB: 64-row chunk w & 3 of the tile, K-tiles
   // 4(w >> 2) .. +3 of the octet (LDS image [w][K-tile & 3][256 B]); chunks past the last row are clamped (their rows are never stored).
@@ -453,6 +498,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   } while (0)
 
   const int nk = g.K / BKE;
+  conv_at(0);
   issue(P0{}, 0, 0); issue_scales(0); issue(P1{}, 0, 0); issue(P2{}, 0, 0); issue(P3{}, 0, 0);
   rt_vmcnt<T::PB1 + T::PA1>();                 // a0 (+ scales), b0 of tile 0 landed (younger: b1, a1)
   RT_BAR();
@@ -467,6 +513,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     const char* tb = smem + (kt & 1) * T::BUF_BYTES;
     const int nb = (kt & 1) ^ 1;
     const int koff = (kt + 1) * 128;           // bytes
+    conv_at(kt + 1);
     // ---- phase 1: (a0,b0)
     RT_READ_A(0); RT_READ_S(0, kt); RT_READ_B(0);
     issue(P0{}, nb, koff);
@@ -511,8 +558,8 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
 
   const int mrow = m0 + wm * T::WMR + l15;
   const int ncol = n0 + wn * T::WNC + 4 * (lane >> 4);
-  if (g.out_f32) epilogue_tile<true, FP8, T::NI, T::NJ>(g, bidx, mrow, ncol, acc);
-  else epilogue_tile<false, FP8, T::NI, T::NJ>(g, bidx, mrow, ncol, acc, wide_store);
+  if (g.out_f32) epilogue_tile<true, FP8, T::NI, T::NJ, CONV>(g, bidx, mrow, ncol, acc);
+  else epilogue_tile<false, FP8, T::NI, T::NJ, CONV>(g, bidx, mrow, ncol, acc, wide_store);
 }
 
 // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8
@@ -537,7 +584,7 @@ __device__ __forceinline__ void panel_walk(int t, int tiles_m, int tiles_n, int&
 typedef const __attribute__((address_space(4))) Launch* LaunchPtr;
 
 // One geometry for the whole launch (G_ = Geo256: every ordinary launch; Geo288: M x N a whole number of 288x192 tiles).
-template <bool FP8, class G_, bool MX = false>
+template <bool FP8, class G_, bool MX = false, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LaunchPtr Lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -560,7 +607,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pp_kernel(const Launch L) {
   t -= bidx * tiles_per_batch;
   int tm, tn;
   panel_walk(t, G.tiles_m, G.tiles_n, tm, tn);
-  gemm_tile<FP8, G_, MX>(G.g, bidx, tm * G_::BM, tn * G_::BN, G.wide_store != 0, smem);
+  gemm_tile<FP8, G_, MX, CONV>(G.g, bidx, tm * G_::BM, tn * G_::BN, G.wide_store != 0, smem);
 }
 
 // Two geometries in one launch: the 256-wide tiles of every group first, then the narrow tiles (GN_) of the columns the host
@@ -634,7 +681,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   Launch L{};
   L.ngroups = ngroups;
   int total = 0;
-  bool mx = false;
+  bool mx = false, conv = false;
   const int bke = fp8 ? 128 : BK;                     // elements per K-tile
   const int al = fp8 ? 16 : 8;                        // elements per 16 bytes
   const int64_t esz = fp8 ? 1 : 2;
@@ -646,7 +693,7 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     if (g.K % bke != 0 || g.N % 4 != 0) return RT_E_SHAPE;
     if (g.rows_per_batch > 0 && g.M % g.rows_per_batch != 0) return RT_E_SHAPE;
     if (!RT_ALIGNED(g.A, 16) || !RT_ALIGNED(g.W, 16) || g.lda % al || g.ldw % al || g.strideA % al) return RT_E_ALIGN;
-    if (g.lda < g.K || g.ldw < g.K || g.ldc < g.N) return RT_E_SHAPE;
+    if ((g.conv_ks == 0 && g.lda < g.K) || g.ldw < g.K || g.ldc < g.N) return RT_E_SHAPE;
     // staging offsets are 32-bit byte offsets from the (per-batch) operand base
     if (((int64_t)g.M * g.lda) * esz >= ((int64_t)1 << 32) || ((int64_t)g.N * g.ldw) * esz >= ((int64_t)1 << 32)) return RT_E_SHAPE;
     const int cal = g.out_f32 ? 16 : 8;
@@ -672,6 +719,12 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
         if (!RT_ALIGNED(g.c8, 8) || g.ldc8 % 8 || g.stride_c8 % 8 || !RT_ALIGNED(g.c_bscale, 16)) return RT_E_ALIGN;
       }
     }
+    if (g.conv_ks != 0) {                               // convolution form (see gemm_tile): one bf16 problem, rows = haloed pixels
+      if (fp8 || ngroups != 1 || g.batch != 1 || (g.conv_ks != 1 && g.conv_ks != 3)) return RT_E_BADARG;
+      if (g.conv_cin < 64 || g.conv_cin % 64 != 0 || g.lda != g.conv_cin || g.K != g.conv_ks * g.conv_ks * g.conv_cin) return RT_E_SHAPE;
+      if (g.conv_w2 < 3 || g.conv_h2 < 3 || g.M % (g.conv_w2 * g.conv_h2) != 0 || g.M >= (1 << 24)) return RT_E_SHAPE;
+      conv = true;
+    }
     L.grp[i].g = g;
     L.grp[i].tiles_m = (g.M + Geo256::BM - 1) / Geo256::BM;
     L.grp[i].tiles_n = (g.N + Geo256::BN - 1) / Geo256::BN;
@@ -685,6 +738,8 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
     if (!e) e = set_lds(gemm_pp_kernel<true, Geo256>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_pp_kernel<true, Geo256, true>, Geo256::LDS_BYTES + 16384);
     if (!e) e = set_lds(gemm_pp_kernel<false, Geo288>, Geo288::LDS_BYTES);
+    if (!e) e = set_lds(gemm_pp_kernel<false, Geo256, false, true>, Geo256::LDS_BYTES);
+    if (!e) e = set_lds(gemm_pp_kernel<false, Geo128, false, true>, Geo128::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo192>, Geo256::LDS_BYTES);
     if (!e) e = set_lds(gemm_mix_kernel<Geo128>, Geo256::LDS_BYTES);
     if (e) return e;
@@ -694,6 +749,17 @@ static int launch_gemm(const rt_gemm_group* groups, int32_t ngroups, void* strea
   if (fp8) {
     if (mx) hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256, true>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES + 16384, st, L);
     else hipLaunchKernelGGL((gemm_pp_kernel<true, Geo256>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+    return rt_hip_status();
+  }
+  if (conv) {                                           // N <= 128 (the decoder's 1024x1024 stages): the 256x128 tile, no dead columns
+    L.grp[0].g.conv_inv_w2 = 1.0f / (float)groups[0].conv_w2;
+    L.grp[0].g.conv_inv_h2 = 1.0f / (float)groups[0].conv_h2;
+    if (groups[0].N <= 128) {
+      L.grp[0].tiles_n = (groups[0].N + Geo128::BN - 1) / Geo128::BN;
+      hipLaunchKernelGGL((gemm_pp_kernel<false, Geo128, false, true>), dim3(L.grp[0].tiles_m * L.grp[0].tiles_n), dim3(THREADS), Geo128::LDS_BYTES, st, L);
+    } else {
+      hipLaunchKernelGGL((gemm_pp_kernel<false, Geo256, false, true>), dim3(total), dim3(THREADS), Geo256::LDS_BYTES, st, L);
+    }
     return rt_hip_status();
   }
   const int cus = num_cus();

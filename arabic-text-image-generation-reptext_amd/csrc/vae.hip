@@ -11,6 +11,7 @@
 // swizzle as gemm_bf16.hip; a K-tile is 64 channels of one tap, so its A rows are 128-B runs of the input.
 #include "rt_common.h"
 #include <initializer_list>
+#include <stdlib.h>
 
 namespace {
 
@@ -479,7 +480,24 @@ __global__ void glyph_blend_kernel(const float* __restrict__ img, const float* _
   }
 }
 
+namespace {
+int g_conv_variant = -1;        // 1: stride-1 convolutions on the GEMM's convolution form (default), 0: conv_nhwc_kernel for everything
+int conv_variant_now() {
+  if (g_conv_variant < 0) {
+    const char* e = getenv("RT_CONV_GEMM");
+    g_conv_variant = e ? (atoi(e) != 0) : 1;
+  }
+  return g_conv_variant;
+}
+}  // namespace
+
 extern "C" {
+
+int rt_conv2d_variant(int32_t mode) {
+  const int prev = conv_variant_now();
+  if (mode >= 0) g_conv_variant = mode != 0;
+  return prev;
+}
 
 int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y, int32_t B, int32_t Hs,
                    int32_t Ws, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t upsample2x,
@@ -496,6 +514,17 @@ int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* r
   a.Ho = stride == 2 ? Hs / 2 : (upsample2x ? 2 * Hs : Hs);
   a.Wo = stride == 2 ? Ws / 2 : (upsample2x ? 2 * Ws : Ws);
   a.out_f32 = out_f32;
+  // stride 1, no fused upsample, a real channel count, bf16 out: the ping-pong GEMM in its convolution form (gemm_bf16.hip, CONV) —
+  // same K order per output element, so the same bits as conv_nhwc_kernel below (tests/test_vae_real_gpu.py), at GEMM speed.
+  if (conv_variant_now() && stride == 1 && !upsample2x && !out_f32 && Cout >= 64 && (int64_t)B * (Hs + 2) * (Ws + 2) < (1 << 24)) {
+    rt_gemm_group g{};
+    g.A = x; g.W = w; g.C = y; g.bias = bias; g.res = res;
+    g.M = B * (Hs + 2) * (Ws + 2); g.N = Cout; g.K = ksize * ksize * Cin; g.batch = 1;
+    g.lda = Cin; g.ldw = g.K; g.ldc = Cout; g.ldr = Cout;
+    g.gelu_from = Cout; g.alpha = 1.f;
+    g.conv_ks = ksize; g.conv_cin = Cin; g.conv_w2 = Ws + 2; g.conv_h2 = Hs + 2;
+    return rt_gemm_bf16(&g, 1, stream);
+  }
   const int64_t M = (int64_t)B * a.Ho * a.Wo;
   if (M > 0x7fffffff) return RT_E_SHAPE;
   const bool narrow = Cout <= 128;                     // 256x128 tile: every wave has live columns

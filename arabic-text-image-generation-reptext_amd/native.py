@@ -47,6 +47,8 @@ class GemmGroup(C.Structure):
         ("c8", C.c_void_p), ("c_bscale", C.c_void_p),
         ("ldc8", C.c_int64), ("stride_c8", C.c_int64), ("c_bscale_plane", C.c_int64), ("c_bscale_rows", C.c_int64),
         ("c8_from", C.c_int32), ("c_bscale_k0", C.c_int32),
+        ("conv_ks", C.c_int32), ("conv_cin", C.c_int32), ("conv_w2", C.c_int32), ("conv_h2", C.c_int32),
+        ("conv_inv_w2", C.c_float), ("conv_inv_h2", C.c_float),
     ]
 
 
@@ -105,6 +107,7 @@ SIGNATURES.update({
 })
 # hint preparation on the device (csrc/hints.hip)
 SIGNATURES.update({
+    "rt_conv2d_variant": [_i32],
     "rt_canny_ws_bytes": [_i32, _i32],
     "rt_canny_u8": [_vp, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _i32, _vp, _i64, _vp],
     "rt_preprocess_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

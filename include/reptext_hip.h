@@ -99,6 +99,16 @@ typedef struct rt_gemm_group {
   uint8_t* c_bscale;
   int64_t ldc8, stride_c8, c_bscale_plane, c_bscale_rows;
   int32_t c8_from, c_bscale_k0;
+  /* Convolution form (ABI 8; rt_gemm_bf16, one group, batch 1): conv_ks = 1 or 3 turns the problem into a stride-1, pad k/2 convolution
+   * over a zero-haloed NHWC image. A = the image [B][conv_h2][conv_w2][conv_cin] (conv_h2 = H+2, conv_w2 = W+2) read as a matrix of
+   * M = B*conv_h2*conv_w2 pixel rows, lda = conv_cin (% 64 == 0); W = [N][ks][ks][conv_cin], K = ks*ks*conv_cin; C / res / add2 = the
+   * output image in the same haloed pixel order (ldc = its channel count). K-tile kt multiplies channels c0.. of tap (dy,dx) of
+   * every pixel p with the rows of A shifted by (dy-1)*conv_w2 + (dx-1) pixels; rows shifted out of the image read as zero; halo
+   * pixels are computed and NOT stored (the halo of C stays as it is). Replaces torch.nn.functional.conv2d of the AutoencoderKL
+   * ResnetBlock2D / conv_in / shortcut convolutions (A.7); rt_conv2d_nhwc routes its stride-1, non-upsampling calls here.
+   * conv_inv_w2 / conv_inv_h2 are filled in by the library. */
+  int32_t conv_ks, conv_cin, conv_w2, conv_h2;
+  float conv_inv_w2, conv_inv_h2;
 } rt_gemm_group;
 
 int rt_gemm_bf16(const rt_gemm_group* groups /* host */, int32_t ngroups, void* stream);
@@ -286,6 +296,10 @@ int rt_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void
 int rt_conv2d_nhwc(const void* x, const void* w, const void* bias, const void* res, void* y,
                    int32_t B, int32_t Hs, int32_t Ws, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
                    int32_t upsample2x, int32_t out_f32, void* stream);
+/* Which kernel serves rt_conv2d_nhwc's stride-1, non-upsampling, bf16-output calls with Cout >= 64 (speed only: both accumulate every
+ * output element in the same K order, results are bit-identical): 1 (default, env RT_CONV_GEMM) = rt_gemm_bf16's convolution form,
+ * 0 = conv_nhwc_kernel. mode >= 0 sets it, mode < 0 only queries; returns the previous mode. */
+int rt_conv2d_variant(int32_t mode);
 /* Row softmax for the VAE mid-block attention (1 head, Dh = 512, computed as GEMM -> softmax -> GEMM):
  * p[r][:] = softmax(scale * s[r][:]), f32 in, bf16 out. cols % 4 == 0. */
 int rt_softmax_rows(const float* s, void* p, int32_t rows, int32_t cols, float scale, void* stream);

@@ -71,6 +71,20 @@ def test_conv_kernel_modes(gpu):
         got = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
         assert rel_l2(got, ref + res) < 4e-3, (ks, stride, up)
         assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0    # halo untouched
+        assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+        if stride == 1 and not up:
+            # these calls ran on the GEMM's convolution form (rt_conv2d_variant 1, the default); conv_nhwc_kernel accumulates every
+            # output element in the same K order: the two must agree bit for bit, in place over the residual as the ResnetBlock uses it
+            prev = lib.rt_conv2d_variant(0)
+            try:
+                y0 = rh.clone()
+                native.check("conv", lib.rt_conv2d_nhwc(xh.data_ptr(), wp.data_ptr(), bd.data_ptr(), y0.data_ptr(), y0.data_ptr(), B, H, W, Cin, Cout, ks, 1, 0, 0, st))
+            finally:
+                lib.rt_conv2d_variant(prev)
+            assert prev == 1
+            y1 = rh.clone()
+            native.check("conv", lib.rt_conv2d_nhwc(xh.data_ptr(), wp.data_ptr(), bd.data_ptr(), y1.data_ptr(), y1.data_ptr(), B, H, W, Cin, Cout, ks, 1, 0, 0, st))
+            assert torch.equal(y0, y1) and torch.equal(y1, y)
 
 
 def test_vae_decode(vae_pair, gpu):

@@ -97,6 +97,14 @@ def test_decode_1024_properties_and_no_score_matrix(real_vae, gpu):
     assert torch.equal(u8, vae.decode_packed(packed, 128, 128, output_u8=True))
     f32 = vae.decode_packed(packed, 128, 128)
     assert bool(torch.isfinite(f32).all())
+    # the stride-1 convolutions ran on the GEMM's convolution form; with conv_nhwc_kernel for all of them the image is the same bits
+    from reptext_amd import native
+    prev = native.load().rt_conv2d_variant(0)
+    try:
+        u8_old = vae.decode_packed(packed, 128, 128, output_u8=True)
+    finally:
+        native.load().rt_conv2d_variant(prev)
+    assert prev == 1 and torch.equal(u8, u8_old)
     hist = torch.bincount(u8.flatten().to(torch.int64), minlength=256).float()
     assert int((hist > 0).sum()) > 64 and float((hist[0] + hist[255]) / hist.sum()) < 0.9 and float(u8.float().std()) > 5
     # mid-block attention alone at 192 x 192 positions
