@@ -413,8 +413,10 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, LDS_PTR(smem + buf * T::BUF_BYTES + lds_off[first + q]), 16,
                                                (CONV && isA) ? (int)src[first + q] + cv_shift : (int)src[first + q], (CONV && isA) ? cv_c0 : koff, 0, 0);
   };
-  // MX: the scale piece of K-tile octet `oct` -> ring slot oct & 1. Wave w copies 1 KiB: 64-row chunk w & 3 of the tile, K-tiles
-  // 4(w >> 2) .. +3 of the octet (LDS image [w][K-tile & 3][256 B]); chunks past the last row are clamped (their rows are never stored).
+  // MX: the scale piece of K-tile octet `oct` -> ring slot oct & 1. Wave w copies the 1 KiB of K-tile w of the octet: the 256 bytes of
+  // each of the tile's four 64-row chunks (lane group l >> 4 = chunk; 2 KiB apart in the plane), so that the LDS image is K-tile-major —
+  // [K-tile & 15][chunk][256 B] over both slots — and a K-tile's offset is ONE shift-and-mask of kt (the chunk-major image needed nine
+  // scalar operations per read: +3 % at K = 15360). Chunks past the last row are clamped (their rows are never stored).
   constexpr int SC_OFF = 2 * T::BUF_BYTES;
   // The base pointer and the plane size are detached from the kernel-argument struct by an opaque asm: otherwise hipcc, short of
   // SGPRs in this loop, re-materialises them from the spilled struct — 16 v_readlane_b32 in every odd K-tile (+9 % at K = 15360).
@@ -427,8 +429,8 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     sc_plane = (int)g.a_bscale_plane;
     asm volatile("" : "+s"(sc_lo), "+s"(sc_hi), "+s"(sc_plane));
     const int64_t row_b = (int64_t)bidx * g.a_bscale_rows;             // multiple of 64 (host check), m0 is a multiple of 256
-    const int chunk = (int)min((row_b + m0) / 64 + (wave & 3), (row_b + g.M - 1) / 64);
-    sc_src = chunk * 2048 + (wave >> 2) * 1024 + lane * 16;
+    const int chunk = (int)min((row_b + m0) / 64 + (lane >> 4), (row_b + g.M - 1) / 64);
+    sc_src = chunk * 2048 + wave * 256 + (lane & 15) * 16;
   }
   auto issue_scales = [&](int oct) {
     if constexpr (MX) {
@@ -446,7 +448,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
   const int sw = (lane >> 1) & 7;
   const int rd0 = l15 * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
-  const int sc_rd = SC_OFF + wm * 2048 + l15 * 16 + (lane >> 4) * 4;         // MX: + slot*8192 + (K-tile & 4)*1024 + a-half*1024 + (K-tile & 3)*256
+  const int sc_rd = SC_OFF + wm * 512 + l15 * 16 + (lane >> 4) * 4;          // MX: + (K-tile & 15)*1024 + a-half*256
   const int a_base = wm * T::WMR * 128;
   const int w_base = T::A_BYTES + wn * T::WNC * 128;
 
@@ -467,7 +469,7 @@ __device__ __forceinline__ void gemm_tile(const rt_gemm_group& g, int bidx, int 
     af[i][1] = *reinterpret_cast<const bf16x8*>(tb + a_base + ((ah)*T::NI0 + i) * 2048 + rd1);                     \
   }
 #define RT_READ_S(ah, kt_)                                                                                        \
-  if constexpr (MX) sc = *reinterpret_cast<const int*>(smem + sc_rd + (((kt_) >> 3) & 1) * 8192 + ((kt_) & 4) * 1024 + (ah)*1024 + ((kt_) & 3) * 256);
+  if constexpr (MX) sc = *reinterpret_cast<const int*>(smem + sc_rd + (((kt_) & 15) << 10) + (ah)*256);
 #define RT_READ_B(bh)                                                                                             \
   _Pragma("unroll") for (int j = 0; j < RT_NJH(bh); ++j) {                                                        \
     wf[bh][j][0] = *reinterpret_cast<const bf16x8*>(tb + w_base + ((bh)*T::NJ0 + j) * 2048 + rd0);                 \

@@ -3,7 +3,7 @@ what. variants listed below."""
 import os, re, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(root, "arabic-text-image-generation-reptext_amd", "csrc")
-for name in (sys.argv[1:] or ("OPSEL0", "NOREAD", "NODMA")):
+for name in (sys.argv[1:] or ("OPSEL0", "NOREAD", "NODMA", "FIXADDR")):
     dst = os.path.join(root, "tools", "mx_dev", "lib_" + name)
     shutil.rmtree(dst, ignore_errors=True)
     shutil.copytree(src, os.path.join(dst, "csrc"), ignore=shutil.ignore_patterns("build"))
@@ -15,7 +15,9 @@ for name in (sys.argv[1:] or ("OPSEL0", "NOREAD", "NODMA")):
     if name == "NOREAD":                   # no ds_read_b32 of the scales: constant 2^0 operand
         s = s.replace("if constexpr (MX) sc = *reinterpret_cast<const int*>(smem + sc_rd", "if constexpr (false) sc = *reinterpret_cast<const int*>(smem + sc_rd")
     if name == "NODMA":                    # the scale piece is never issued
-        s = s.replace("if constexpr (MX) { if (kt & 1) issue_scales((kt + 1) >> 1); }", "")
+        s = s.replace("if constexpr (MX) { if ((kt & 7) == 7) issue_scales((kt + 1) >> 3); }", "")
+    if name == "FIXADDR":                  # the scale dword is read from a K-tile-independent address (wrong values; timing only)
+        s = s.replace("(((kt_) & 15) << 10) + (ah)*256);", "(ah)*256);")
     assert s != n0, name
     open(p, "w").write(s)
     subprocess.check_call(["make", "-s", "-C", os.path.join(dst, "csrc"), "ROOT=" + root], stderr=subprocess.DEVNULL)
